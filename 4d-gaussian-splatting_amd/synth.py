@@ -1,0 +1,146 @@
+"""Seeded synthetic 4D Gaussian scenes + camera.
+
+The reference ships no data; this generator is grounded in its own
+initialisation (xyz ~ U[-1.3,1.3]^3 as scene/dataset_readers.py:329, unit
+quaternions and scales_t as scene/gaussian_model.py:268-286) and its camera
+conventions (utils/graphics_utils.py:38-72, scene/cameras.py:65-71: matrices
+are stored transposed, "row-vector" convention, and read column-major by the
+kernels).  Everything is generated on the CPU from a seeded generator so the
+tensors are identical on every device; callers move them with ``.to(device)``.
+"""
+import math
+from typing import Dict, NamedTuple
+
+import numpy as np
+import torch
+
+
+class SceneConfig(NamedTuple):
+    name: str
+    P: int
+    W: int
+    H: int
+    sh_degree: int
+    sh_degree_t: int
+    s0: float          # base spatial scale
+    duration: float    # time_duration
+    rot_4d: bool
+    gaussian_dim: int
+    force_sh_3d: bool
+
+
+# BASELINE.json configs[0..4]
+CONFIGS: Dict[str, SceneConfig] = {
+    "C1": SceneConfig("C1", 10_000, 400, 400, 0, 0, 0.03, 1.0, True, 4, True),
+    "C2": SceneConfig("C2", 100_000, 800, 800, 3, 0, 0.02, 1.0, True, 4, True),
+    "C3": SceneConfig("C3", 300_000, 1352, 1014, 3, 2, 0.015, 10.0, True, 4, False),
+    "C5": SceneConfig("C5", 2_000_000, 2704, 2028, 3, 0, 0.006, 1.0, True, 4, True),
+}
+
+
+def num_sh_coeffs(sh_degree: int, sh_degree_t: int, force_sh_3d: bool, gaussian_dim: int) -> int:
+    """Coefficients per Gaussian, scene/gaussian_model.py:222-228 (4D-SH: (D+1)^2 * (D_t+1))."""
+    m = (sh_degree + 1) ** 2
+    if gaussian_dim == 4 and not force_sh_3d:
+        m *= (sh_degree_t + 1)
+    return m
+
+
+def make_camera(W: int, H: int, focal: float = None, cam_z: float = -4.0,
+                znear: float = 0.01, zfar: float = 100.0) -> Dict[str, object]:
+    """Camera at (0,0,cam_z) looking down +z.
+
+    Returns the tensors exactly as the reference Camera holds them
+    (scene/cameras.py:65-71): world_view_transform and full_proj_transform are
+    the transposes of the mathematical (column-vector) matrices.
+    """
+    if focal is None:
+        focal = 0.9 * W
+    tanfovx = W / (2.0 * focal)
+    tanfovy = H / (2.0 * focal)
+    # world -> view, R = I, t = -C  (utils/graphics_utils.py:38-50)
+    Rt = np.eye(4, dtype=np.float64)
+    Rt[2, 3] = -cam_z
+    V = torch.tensor(np.float32(Rt))
+    # perspective (utils/graphics_utils.py:52-72)
+    top = tanfovy * znear
+    right = tanfovx * znear
+    Pm = torch.zeros(4, 4)
+    Pm[0, 0] = 2.0 * znear / (2.0 * right)
+    Pm[1, 1] = 2.0 * znear / (2.0 * top)
+    Pm[3, 2] = 1.0
+    Pm[2, 2] = zfar / (zfar - znear)
+    Pm[2, 3] = -(zfar * znear) / (zfar - znear)
+    world_view = V.transpose(0, 1).contiguous()
+    proj = Pm.transpose(0, 1).contiguous()
+    full = (world_view.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
+    campos = world_view.inverse()[3, :3].contiguous()
+    return {
+        "image_width": W, "image_height": H,
+        "tanfovx": tanfovx, "tanfovy": tanfovy,
+        "FoVx": 2.0 * math.atan(tanfovx), "FoVy": 2.0 * math.atan(tanfovy),
+        "world_view_transform": world_view, "full_proj_transform": full,
+        "camera_center": campos,
+    }
+
+
+def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H: int = None,
+               random_flow: bool = False, bg=(0.0, 0.0, 0.0), timestamp_frac: float = 0.5) -> Dict[str, object]:
+    """Post-activation rasterizer inputs for ``cfg`` (CPU float32 tensors).
+
+    Keys mirror GaussianRasterizer.forward's arguments
+    (gaussian_renderer/diff_gaussian_rasterization.py:263-267) plus the settings.
+    """
+    P = cfg.P if P is None else P
+    W = cfg.W if W is None else W
+    H = cfg.H if H is None else H
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dur = cfg.duration
+
+    def randn(*s):
+        return torch.randn(*s, generator=g, dtype=torch.float32)
+
+    def rand(*s):
+        return torch.rand(*s, generator=g, dtype=torch.float32)
+
+    xyz = (rand(P, 3) * 2.0 - 1.0) * 1.3
+    ts = (rand(P, 1) * 1.2 - 0.1) * dur
+    scales = cfg.s0 * torch.exp(0.3 * randn(P, 3))
+    scales_t = math.sqrt(0.2) * torch.exp(0.3 * randn(P, 1)) * dur
+    ident = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    rot = torch.nn.functional.normalize(ident + 0.05 * randn(P, 4), dim=1)
+    rot_r = torch.nn.functional.normalize(ident + 0.05 * randn(P, 4), dim=1)
+    opacity = torch.sigmoid(randn(P, 1))
+    M = num_sh_coeffs(cfg.sh_degree, cfg.sh_degree_t, cfg.force_sh_3d, cfg.gaussian_dim)
+    shs = 0.2 * randn(P, M, 3)
+    shs[:, 0, :] = rand(P, 3) * 2.0 - 1.0
+    flow = 0.5 * randn(P, 2) if random_flow else torch.zeros(P, 2)
+    cam = make_camera(W, H)
+    scene = {
+        "cfg": cfg, "P": P, "W": W, "H": H, "M": M,
+        "means3D": xyz.contiguous(), "ts": ts.contiguous(),
+        "scales": scales.contiguous(), "scales_t": scales_t.contiguous(),
+        "rotations": rot.contiguous(), "rotations_r": rot_r.contiguous(),
+        "opacities": opacity.contiguous(), "shs": shs.contiguous(),
+        "flow_2d": flow.contiguous(),
+        "bg": torch.tensor(bg, dtype=torch.float32),
+        "sh_degree": cfg.sh_degree, "sh_degree_t": cfg.sh_degree_t,
+        "timestamp": float(timestamp_frac * dur), "time_duration": float(dur),
+        "rot_4d": cfg.rot_4d, "gaussian_dim": cfg.gaussian_dim, "force_sh_3d": cfg.force_sh_3d,
+        "scale_modifier": 1.0, "prefilter_var": -1.0,
+    }
+    scene.update(cam)
+    return scene
+
+
+def make_upstream_grads(W: int, H: int, seed: int = 1, scale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Seeded upstream gradients for (color, depth, alpha, flow)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+
+    def randn(*s):
+        return torch.randn(*s, generator=g, dtype=torch.float32) * scale
+
+    return {
+        "grad_color": randn(3, H, W), "grad_depth": randn(1, H, W),
+        "grad_alpha": randn(1, H, W), "grad_flow": randn(2, H, W),
+    }
