@@ -1,0 +1,133 @@
+"""ctypes binding of libfdgs.so (C ABI: include/fdgs.h).
+
+This is the thin host glue the north star asks for: PyTorch owns every tensor
+and the current HIP stream; the library only borrows raw device pointers.  It
+plays the role of the reference's pybind module ``_C``
+(diff-gaussian-rasterization/ext.cpp:15-19) and of the tensor allocation code in
+rasterize_points.cu:36-149, 151-270.
+
+There is NO fallback: if the shared library has not been built
+(``4d-gaussian-splatting_amd/csrc/build.sh`` or ``__graft_entry__.build()``) the
+import of this module raises, and every entry point raises if handed CPU tensors.
+"""
+import ctypes as C
+import os
+
+import torch  # must be imported before libfdgs.so so both share one HIP runtime (same SONAME)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfdgs.so")
+
+FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
+
+_fp = C.c_void_p  # all device pointers travel as void*
+
+
+class FdgsScene(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("D_t", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("bg", _fp), ("means3D", _fp), ("shs", _fp), ("colors_precomp", _fp), ("flows", _fp), ("opacities", _fp),
+        ("ts", _fp), ("scales", _fp), ("scales_t", _fp), ("rotations", _fp), ("rotations_r", _fp),
+        ("cov3D_precomp", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp),
+        ("scale_modifier", C.c_float), ("prefilter_var", C.c_float),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+        ("timestamp", C.c_float), ("time_duration", C.c_float),
+        ("rot_4d", C.c_int32), ("gaussian_dim", C.c_int32), ("force_sh_3d", C.c_int32),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+    ]
+
+
+class FdgsForwardOut(C.Structure):
+    _fields_ = [("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
+                ("out_means3D", _fp), ("covs_com", _fp)]
+
+
+class FdgsBackwardIn(C.Structure):
+    _fields_ = [("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_alpha", _fp), ("dL_dout_flow", _fp),
+                ("radii", _fp), ("out_means3D", _fp), ("geom_buffer", _fp), ("binning_buffer", _fp),
+                ("image_buffer", _fp), ("num_rendered", C.c_int32)]
+
+
+class FdgsBackwardOut(C.Structure):
+    _fields_ = [("dL_dmeans2D", _fp), ("dL_dcolors", _fp), ("dL_dopacity", _fp), ("dL_dmeans3D", _fp),
+                ("dL_dcov3D", _fp), ("dL_dsh", _fp), ("dL_dflows", _fp), ("dL_dts", _fp), ("dL_dscales", _fp),
+                ("dL_dscales_t", _fp), ("dL_drotations", _fp), ("dL_drotations_r", _fp), ("dL_dconic", _fp)]
+
+
+class FdgsDebugView(C.Structure):
+    _fields_ = [("depths", _fp), ("records", _fp), ("cov3D", _fp), ("tiles_touched", _fp), ("clamped", _fp),
+                ("depth_order", _fp), ("point_list", _fp), ("tile_keys", _fp), ("ranges", _fp), ("n_contrib", _fp),
+                ("final_T", _fp)]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+
+# every symbol include/fdgs.h declares
+EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_last_error", "fdgs_version")
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libfdgs.so not found at %s -- build it with 4d-gaussian-splatting_amd/csrc/build.sh "
+            "(or __graft_entry__.build()); there is no CPU / PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.fdgs_rasterize_forward.argtypes = [C.POINTER(FdgsScene), C.POINTER(FdgsForwardOut), ALLOC_FN, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_int32)]
+    lib.fdgs_rasterize_forward.restype = C.c_int
+    lib.fdgs_rasterize_backward.argtypes = [C.POINTER(FdgsScene), C.POINTER(FdgsBackwardIn),
+                                            C.POINTER(FdgsBackwardOut), C.c_void_p]
+    lib.fdgs_rasterize_backward.restype = C.c_int
+    lib.fdgs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fdgs_mark_visible.restype = C.c_int
+    lib.fdgs_geometry_bytes.argtypes = [C.c_int32]
+    lib.fdgs_geometry_bytes.restype = C.c_size_t
+    lib.fdgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.fdgs_image_bytes.restype = C.c_size_t
+    lib.fdgs_binning_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.fdgs_binning_bytes.restype = C.c_size_t
+    lib.fdgs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(FdgsDebugView)]
+    lib.fdgs_debug_views.restype = C.c_int
+    lib.fdgs_last_error.restype = C.c_char_p
+    lib.fdgs_version.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.fdgs_last_error().decode()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = last_error()
+        if rc == 1:
+            # argument errors keep the reference's Python-level wording / type
+            # (gaussian_renderer/diff_gaussian_rasterization.py:271-280 raise plain Exception)
+            raise Exception(msg)
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def _ptr(t):
+    """Device pointer of a tensor; None / empty tensor -> NULL (the reference's absent-tensor convention)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _dev_f32(t, name):
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("fdgs: tensor '%s' must live on the GPU (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def current_stream_handle(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,75 @@
+// blend_common.h -- pieces shared by the forward and backward blend kernels (gfx950, wave64).
+//
+// Work decomposition: one wave64 (= one 64-thread workgroup) owns one 8x8 pixel
+// block, four blocks per 16x16 tile.  The tile list itself (point_list / ranges) is
+// the reference's AABB list, bit-identical to the oracle; what changes is how a wave
+// consumes it: each lane fetches ONE list entry, tests whether that Gaussian can
+// reach alpha >= 1/255 anywhere inside the wave's pixel block (exact minimum of the
+// conic quadratic over the block rectangle, conservative slack), and the survivors
+// are ballot-compacted into a wave-private LDS queue.  On the C3 workload only ~43 %
+// of (entry, block) pairs survive, and every survivor costs the 64 lanes the full
+// per-pixel evaluation, so the test (done once per entry by one lane) removes more
+// than half of the blend arithmetic without changing a single pixel: an entry is
+// dropped only if the per-pixel test (alpha < 1/255, reference forward.cu:590) would
+// have rejected it for every pixel of the block.  List positions are kept so
+// n_contrib keeps the reference's meaning (position in the full tile list).
+#pragma once
+#include "fdgs_common.h"
+
+namespace fdgs
+{
+	constexpr int BLK = 8;        // pixel block edge per wave
+	constexpr int NUM_XCDS = 8;
+
+	__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+	struct BlockId { int tile, sub; };
+	// Workgroup id -> (tile, 8x8 sub-block).  Workgroups are dealt round-robin to the 8 XCDs
+	// (id % 8); give each XCD a contiguous band of tiles and keep the 4 sub-blocks of a tile on
+	// one XCD so the shared list and records stay in one L2.
+	__device__ __forceinline__ BlockId block_of(int wg, int ntiles)
+	{
+		const int chunk = (ntiles + NUM_XCDS - 1) / NUM_XCDS;
+		const int xcd = wg % NUM_XCDS, k = wg / NUM_XCDS;
+		BlockId b;
+		b.tile = xcd * chunk + (k >> 2); // may be >= ntiles for the last XCD: caller returns
+		b.sub = k & 3;
+		return b;
+	}
+	static inline int blend_grid(int ntiles) { return div_up(ntiles, NUM_XCDS) * NUM_XCDS * 4; }
+
+	// Can the Gaussian (record words a = (x, y, conic.x, conic.y), b = (conic.z, opacity, ..))
+	// reach alpha >= 1/255 at some point of the rectangle [rx0,rx1] x [ry0,ry1] (pixel centres)?
+	// alpha = opacity * exp(-q), q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  ==>  need min q <= ln(255 opacity).
+	// The minimum of the convex q over the rectangle is 0 if the mean is inside, otherwise it lies
+	// on one of the four edges (1-D quadratics, clamped).  Slack 0.05 in q (5 % in alpha) covers
+	// every rounding difference to the per-pixel evaluation; degenerate conics are never culled.
+	__device__ __forceinline__ bool block_reaches(const float4 a, const float4 b, float rx0, float rx1, float ry0, float ry1)
+	{
+		const float A = a.z, B = a.w, Cc = b.x, op = b.y;
+		if (!(op >= 0.0039f)) return false;                 // alpha <= opacity < 1/255 (1/255 = 0.003922)
+		if (!(A > 0.0f && Cc > 0.0f)) return true;
+		const float tau = __logf(255.0f * op) + 0.05f;
+		const float dx0 = rx0 - a.x, dx1 = rx1 - a.x, dy0 = ry0 - a.y, dy1 = ry1 - a.y;
+		if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
+		const float invA = __builtin_amdgcn_rcpf(A), invC = __builtin_amdgcn_rcpf(Cc);
+		float qmin;
+		{
+			const float dy = fminf(fmaxf(-B * dx0 * invC, dy0), dy1);
+			qmin = 0.5f * (A * dx0 * dx0 + Cc * dy * dy) + B * dx0 * dy;
+		}
+		{
+			const float dy = fminf(fmaxf(-B * dx1 * invC, dy0), dy1);
+			qmin = fminf(qmin, 0.5f * (A * dx1 * dx1 + Cc * dy * dy) + B * dx1 * dy);
+		}
+		{
+			const float dx = fminf(fmaxf(-B * dy0 * invA, dx0), dx1);
+			qmin = fminf(qmin, 0.5f * (A * dx * dx + Cc * dy0 * dy0) + B * dx * dy0);
+		}
+		{
+			const float dx = fminf(fmaxf(-B * dy1 * invA, dx0), dx1);
+			qmin = fminf(qmin, 0.5f * (A * dx * dx + Cc * dy1 * dy1) + B * dx * dy1);
+		}
+		return qmin <= tau;
+	}
+}

@@ -1,0 +1,28 @@
+#!/usr/bin/env bash
+# Builds libfdgs.so (C ABI in include/fdgs.h) for gfx950 with hipcc.  In-tree, no GPU needed.
+#   ./build.sh            incremental (per-TU objects under build/)
+#   ./build.sh clean      remove objects and the library
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+ARCH=${FDGS_ARCH:-gfx950}
+OUT=libfdgs.so
+if [[ "${1:-}" == "clean" ]]; then rm -rf build "$OUT"; exit 0; fi
+mkdir -p build
+COMMON="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function"
+# TUs whose float results feed integers (radius / tile rect / depth key bits) or must track the
+# oracle's operation order are built with FP contraction off (no FMA fusion).
+declare -A EXTRA=( [preprocess_fwd]="-ffp-contract=off" [preprocess_bwd]="-ffp-contract=off" )
+OBJS=()
+PIDS=()
+for src in preprocess_fwd binning blend_fwd blend_bwd preprocess_bwd capi; do
+  obj=build/$src.o
+  OBJS+=("$obj")
+  if [[ ! -f $obj || $src.hip -nt $obj || fdgs_common.h -nt $obj || fdgs_math.h -nt $obj || ../../include/fdgs.h -nt $obj ]]; then
+    $HIPCC $COMMON ${EXTRA[$src]:-} ${FDGS_EXTRA_FLAGS:-} -c $src.hip -o $obj &
+    PIDS+=($!)
+  fi
+done
+for p in "${PIDS[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+$HIPCC --offload-arch=$ARCH -shared -fPIC -o $OUT "${OBJS[@]}"
+echo "$(pwd)/$OUT"

@@ -1,0 +1,250 @@
+// capi.hip -- extern "C" entry points of libfdgs.so (declared in include/fdgs.h).
+//
+// Host orchestration of the forward and backward pipelines; the role of
+// CudaRasterizer::Rasterizer::forward / backward (rasterizer_impl.cu:199-364,
+// 368-496) plus the argument checks of rasterize_points.cu:69-71.  Everything is
+// enqueued on the caller's stream; the only host synchronisation is the
+// read-back of num_rendered (4 bytes through a pinned staging word), as in the
+// reference (rasterizer_impl.cu:302).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "fdgs_common.h"
+
+using namespace fdgs;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr, what)                                                                         \
+	do {                                                                                            \
+		hipError_t e__ = (expr);                                                                    \
+		if (e__ != hipSuccess) return fail(FDGS_ERR_HIP, "%s: %s", what, hipGetErrorString(e__));   \
+	} while (0)
+
+// debug mode == the reference's CHECK_CUDA(..., debug): synchronise and check after each stage
+#define STAGE(expr, what)                                                                           \
+	do {                                                                                            \
+		HIP_TRY((expr), what);                                                                      \
+		if (debug) HIP_TRY(hipStreamSynchronize(stream), what);                                     \
+	} while (0)
+
+static int check_scene(const fdgs_scene* s)
+{
+	if (!s) return fail(FDGS_ERR_INVALID_ARG, "scene is NULL");
+	if (s->P < 0 || s->W <= 0 || s->H <= 0) return fail(FDGS_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", s->P, s->W, s->H);
+	if (div_up(s->W, TILE_X) > 65535 || div_up(s->H, TILE_Y) > 65535) return fail(FDGS_ERR_INVALID_ARG, "image too large for 16-bit tile rectangles");
+	if (s->P == 0) return FDGS_OK;
+	if (!s->means3D || !s->opacities || !s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
+		return fail(FDGS_ERR_INVALID_ARG, "means3D / opacities / bg / viewmatrix / projmatrix / campos must not be NULL");
+	// gaussian_renderer/diff_gaussian_rasterization.py:271-280
+	if ((s->shs == nullptr) == (s->colors_precomp == nullptr))
+		return fail(FDGS_ERR_INVALID_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+	if (s->shs && s->M <= 0) return fail(FDGS_ERR_INVALID_ARG, "shs given but M == 0");
+	if (s->cov3D_precomp == nullptr)
+	{
+		if (!s->scales || !s->rotations)
+			return fail(FDGS_ERR_INVALID_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+		if (s->rot_4d && (!s->rotations_r || !s->scales_t || !s->ts))
+			return fail(FDGS_ERR_INVALID_ARG, "Please provide exactly rotations_r and scales_t and ts if rot_4d and cov3D_precomp is None!");
+		if (!s->rot_4d && s->gaussian_dim == 4 && (!s->scales_t || !s->ts))
+			return fail(FDGS_ERR_INVALID_ARG, "gaussian_dim == 4 needs scales_t and ts");
+	}
+	if (s->shs && !(s->gaussian_dim == 3 || s->force_sh_3d))
+	{
+		if (!s->ts) return fail(FDGS_ERR_INVALID_ARG, "4D SH needs ts");
+		const int need = (s->D > 2) ? 16 * (1 + (s->D_t > 2 ? 2 : (s->D_t > 0 ? s->D_t : 0))) : (s->D + 1) * (s->D + 1);
+		if (s->M < need) return fail(FDGS_ERR_INVALID_ARG, "M=%d too small for D=%d D_t=%d", s->M, s->D, s->D_t);
+	}
+	else if (s->shs && s->M < (s->D + 1) * (s->D + 1))
+		return fail(FDGS_ERR_INVALID_ARG, "M=%d too small for D=%d", s->M, s->D);
+	return FDGS_OK;
+}
+
+extern "C" size_t fdgs_geometry_bytes(int32_t P) { return geom_layout(P).total; }
+extern "C" size_t fdgs_image_bytes(int32_t W, int32_t H) { return image_layout(W, H).total; }
+extern "C" size_t fdgs_binning_bytes(int32_t R, int32_t, int32_t) { return bin_layout(R).total; }
+extern "C" const char* fdgs_last_error(void) { return g_err; }
+extern "C" int fdgs_version(void) { return FDGS_VERSION; }
+
+// which ping-pong buffer holds the sorted output after `passes` radix passes
+static inline int final_buf(int passes) { return passes & 1; }
+
+extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
+                                      fdgs_alloc_fn alloc, void* alloc_user, void* stream_v, int32_t* num_rendered)
+{
+	g_err[0] = 0;
+	int rc = check_scene(scene);
+	if (rc != FDGS_OK) return rc;
+	if (!out || !alloc || !num_rendered) return fail(FDGS_ERR_INVALID_ARG, "out / alloc / num_rendered must not be NULL");
+	const fdgs_scene& s = *scene;
+	hipStream_t stream = (hipStream_t)stream_v;
+	const bool debug = s.debug != 0;
+	const int P = s.P, W = s.W, H = s.H;
+	const int gx = div_up(W, TILE_X), gy = div_up(H, TILE_Y), T = gx * gy;
+	const size_t N = (size_t)W * H;
+	if (!out->out_color || !out->out_flow || !out->out_depth || !out->out_T || (P > 0 && (!out->radii || !out->out_means3D)))
+		return fail(FDGS_ERR_INVALID_ARG, "forward outputs must not be NULL");
+	*num_rendered = 0;
+
+	const GeomLayout GL = geom_layout(P);
+	const ImageLayout IL = image_layout(W, H);
+	char* geom = (char*)alloc(alloc_user, FDGS_BUF_GEOMETRY, GL.total);
+	char* img = (char*)alloc(alloc_user, FDGS_BUF_IMAGE, IL.total);
+	if (!geom || !img) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL");
+	float* final_T = (float*)(img + IL.final_T);
+	uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
+	uint32_t* ranges = (uint32_t*)(img + IL.ranges);
+
+	int R = 0;
+	uint32_t* point_list = nullptr;
+	if (P > 0)
+	{
+		STAGE(launch_preprocess_fwd(s, *out, geom, stream), "preprocess_fwd");
+
+		uint32_t* dk[2] = { (uint32_t*)(geom + GL.sort_key[0]), (uint32_t*)(geom + GL.sort_key[1]) };
+		uint32_t* dv[2] = { (uint32_t*)(geom + GL.sort_val[0]), (uint32_t*)(geom + GL.sort_val[1]) };
+		int dres = 0;
+		STAGE(radix_sort_pairs(dk, dv, P, 0, 32, (uint32_t*)(geom + GL.hist), stream, &dres), "depth sort");
+		const uint32_t* order = dv[dres];
+
+		uint32_t* block_sums = (uint32_t*)(geom + GL.scan_block);
+		STAGE(launch_offsets_scan((const uint32_t*)(geom + GL.tiles_touched), order, P,
+		                          (uint32_t*)(geom + GL.offsets), block_sums, stream), "offset scan");
+
+		// num_rendered read-back (the one host sync of the forward pass)
+		static thread_local uint32_t* pinned = nullptr;
+		if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault), "hipHostMalloc");
+		HIP_TRY(hipMemcpyAsync(pinned, block_sums + div_up(P, SCAN_CHUNK), 4, hipMemcpyDeviceToHost, stream), "num_rendered copy");
+		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
+		R = (int)*pinned;
+		if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
+	}
+	*num_rendered = R;
+
+	const BinLayout BL = bin_layout(R);
+	char* bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
+	if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+
+	if (R > 0)
+	{
+		uint32_t* tk[2] = { (uint32_t*)(bin + BL.key[0]), (uint32_t*)(bin + BL.key[1]) };
+		uint32_t* tv[2] = { (uint32_t*)(bin + BL.val[0]), (uint32_t*)(bin + BL.val[1]) };
+		const int dres = final_buf(4);
+		STAGE(launch_emit_instances((const uint32_t*)(geom + GL.sort_val[dres]), (const uint32_t*)(geom + GL.offsets),
+		                            (const uint16_t*)(geom + GL.rect), P, R, gx, tk[0], tv[0], stream), "emit instances");
+		int tres = 0;
+		STAGE(radix_sort_pairs(tk, tv, R, 0, tile_sort_passes(T) * RADIX_BITS, (uint32_t*)(bin + BL.hist), stream, &tres), "tile sort");
+		STAGE(launch_tile_ranges(tk[tres], R, T, ranges, stream), "tile ranges");
+		point_list = tv[tres];
+	}
+	else
+		STAGE(hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
+
+	fdgs_scene s2 = s;
+	if (P == 0)
+	{
+		// nothing to blend: the kernel still writes background colour / T = 1 everywhere
+		static const uint32_t dummy = 0; (void)dummy;
+	}
+	STAGE(launch_blend_fwd(s2, *out, (const float*)(geom + GL.records), point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
+	(void)N;
+	return FDGS_OK;
+}
+
+extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,
+                                       const fdgs_backward_out* out, void* stream_v)
+{
+	g_err[0] = 0;
+	int rc = check_scene(scene);
+	if (rc != FDGS_OK) return rc;
+	if (!in || !out) return fail(FDGS_ERR_INVALID_ARG, "in / out must not be NULL");
+	const fdgs_scene& s = *scene;
+	hipStream_t stream = (hipStream_t)stream_v;
+	const bool debug = s.debug != 0;
+	const int P = s.P, W = s.W, H = s.H;
+	if (P == 0) return FDGS_OK;
+	if (!in->dL_dout_color || !in->dL_dout_depth || !in->dL_dout_alpha || !in->dL_dout_flow ||
+	    !in->radii || !in->out_means3D || !in->geom_buffer || !in->binning_buffer || !in->image_buffer)
+		return fail(FDGS_ERR_INVALID_ARG, "backward inputs must not be NULL");
+	if (!out->dL_dmeans2D || !out->dL_dcolors || !out->dL_dopacity || !out->dL_dmeans3D || !out->dL_dcov3D ||
+	    !out->dL_dflows || !out->dL_dconic || (s.shs && !out->dL_dsh))
+		return fail(FDGS_ERR_INVALID_ARG, "backward outputs must not be NULL");
+	if (s.cov3D_precomp == nullptr)
+	{
+		if (!out->dL_dscales || !out->dL_drotations) return fail(FDGS_ERR_INVALID_ARG, "dL_dscales / dL_drotations must not be NULL");
+		if (s.rot_4d && (!out->dL_dscales_t || !out->dL_drotations_r || !out->dL_dts))
+			return fail(FDGS_ERR_INVALID_ARG, "dL_dscales_t / dL_drotations_r / dL_dts must not be NULL for rot_4d");
+	}
+	const int gx = div_up(W, TILE_X), gy = div_up(H, TILE_Y), T = gx * gy;
+	const int R = in->num_rendered;
+	const GeomLayout GL = geom_layout(P);
+	const ImageLayout IL = image_layout(W, H);
+	const BinLayout BL = bin_layout(R);
+	const char* geom = (const char*)in->geom_buffer;
+	const char* img = (const char*)in->image_buffer;
+	const char* bin = (const char*)in->binning_buffer;
+	const int tres = final_buf(tile_sort_passes(T));
+	const uint32_t* point_list = (const uint32_t*)(bin + BL.val[tres]);
+
+	// the five atomically-accumulated per-Gaussian gradients start from zero
+	STAGE(hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, stream), "memset");
+	STAGE(hipMemsetAsync(out->dL_dconic, 0, (size_t)P * 16, stream), "memset");
+	STAGE(hipMemsetAsync(out->dL_dopacity, 0, (size_t)P * 4, stream), "memset");
+	STAGE(hipMemsetAsync(out->dL_dcolors, 0, (size_t)P * 12, stream), "memset");
+	STAGE(hipMemsetAsync(out->dL_dflows, 0, (size_t)P * 8, stream), "memset");
+
+	if (R > 0)
+		STAGE(launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
+		                       (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
+	STAGE(launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
+	return FDGS_OK;
+}
+
+extern "C" int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                 uint8_t* present, void* stream_v)
+{
+	g_err[0] = 0;
+	(void)projmatrix;
+	if (P < 0) return fail(FDGS_ERR_INVALID_ARG, "P < 0");
+	if (P == 0) return FDGS_OK;
+	if (!means3D || !viewmatrix || !present) return fail(FDGS_ERR_INVALID_ARG, "NULL argument");
+	HIP_TRY(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_v), "mark_visible");
+	return FDGS_OK;
+}
+
+extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
+                                const void* geom_v, const void* bin_v, const void* img_v, fdgs_debug_view* v)
+{
+	g_err[0] = 0;
+	if (!v || !geom_v || !img_v) return fail(FDGS_ERR_INVALID_ARG, "NULL argument");
+	const GeomLayout GL = geom_layout(P);
+	const ImageLayout IL = image_layout(W, H);
+	const BinLayout BL = bin_layout(R);
+	const int T = div_up(W, TILE_X) * div_up(H, TILE_Y);
+	const char* geom = (const char*)geom_v;
+	const char* bin = (const char*)bin_v;
+	const char* img = (const char*)img_v;
+	v->depths = (const float*)(geom + GL.depths);
+	v->records = (const float*)(geom + GL.records);
+	v->cov3D = (const float*)(geom + GL.cov3D);
+	v->tiles_touched = (const uint32_t*)(geom + GL.tiles_touched);
+	v->clamped = (const uint8_t*)(geom + GL.clamped);
+	v->depth_order = (const uint32_t*)(geom + GL.sort_val[final_buf(4)]);
+	const int tres = final_buf(tile_sort_passes(T));
+	v->point_list = bin ? (const uint32_t*)(bin + BL.val[tres]) : nullptr;
+	v->tile_keys = bin ? (const uint32_t*)(bin + BL.key[tres]) : nullptr;
+	v->ranges = (const uint32_t*)(img + IL.ranges);
+	v->n_contrib = (const uint32_t*)(img + IL.n_contrib);
+	v->final_T = (const float*)(img + IL.final_T);
+	return FDGS_OK;
+}

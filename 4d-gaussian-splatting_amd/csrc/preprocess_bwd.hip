@@ -1,0 +1,501 @@
+// preprocess_bwd.hip -- fused per-Gaussian backward (gfx950).
+//
+// One kernel does what the reference does in two (computeCov2DCUDA backward.cu:486-617,
+// then preprocessCUDA backward.cu:839-923 with computeColorFromSH[_4D] :20-481,
+// computeCov3D :621-684, computeCov3D_conditional :689-834): the conic gradient ->
+// cov2D -> cov3D + view-space mean gradient, the projection Jacobian, the SH /
+// 4D-SH backward, and the covariance backward to scales / scale_t / rotations /
+// rotation_r / t, including the marginal-opacity chain.  Fusing keeps dL_dcov3D
+// and dL_dmean3D in registers between the two halves, and every output is
+// written for every Gaussian (zeros for culled ones), so the caller never
+// pre-zeroes the ~180 floats per Gaussian the reference memsets
+// (rasterize_points.cu:201-213).
+//
+// Bug-compatible with the reference backward:
+//   Q1  dL_dsh[1] uses the degree-0 basis in the 4D path      (backward.cu:190)
+//   Q2  d cos / dt has the wrong sign                          (backward.cu:303,384)
+//   Q3  the k=2 time term overwrites the k=1 term in dRGBdt    (backward.cu:403)
+//   Q4  SH view direction from the SHIFTED mean (forward uses the input mean)
+//   Q5  the whole dL_dmean (incl. SH part) is fed back as dL_d(delta_mean)
+//   Q6  no marginal-opacity backward for gaussian_dim == 4 without rot_4d
+//   Q7  cov12 read as Sigma[3][k] here, Sigma[k][3] in the forward
+#pragma clang fp contract(off)
+#include "fdgs_common.h"
+#include "fdgs_math.h"
+
+namespace fdgs
+{
+	struct BwdArgs
+	{
+		int P, D, D_t, M;
+		const float *shs, *opacities, *ts, *scales, *scales_t, *rotations, *rotations_r, *cov3D_precomp;
+		const float *viewmatrix, *projmatrix, *campos;
+		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
+		int rot_4d, gaussian_dim, force_sh_3d;
+		const int32_t* radii; const float* means; /* out_means3D */
+		const float* cov3D; const uint8_t* clamped;
+		const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor;
+		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dsh, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
+	};
+
+	__device__ __forceinline__ float3 b_ld3(const float* p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+	__device__ __forceinline__ void b_st3(float* p, size_t i, float3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+	__device__ __forceinline__ float3 b_add(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+	__device__ __forceinline__ float3 b_scl(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
+	__device__ __forceinline__ float b_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+	// auxiliary.h:108-118
+	__device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv)
+	{
+		const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+		float3 r;
+		r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+		r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+		r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+		return r;
+	}
+
+	// 3D SH backward (backward.cu:20-139). Writes dL_dsh[0..(deg+1)^2), returns dL/d(dir).
+	__device__ float3 sh_bwd_3d(int deg, const float* __restrict__ sh, float* __restrict__ dsh, float3 dir, float3 dRGB)
+	{
+		float3 dx = make_float3(0, 0, 0), dy = dx, dz = dx;
+		const float x = dir.x, y = dir.y, z = dir.z;
+		b_st3(dsh, 0, b_scl(SH_C0, dRGB));
+		if (deg > 0)
+		{
+			b_st3(dsh, 1, b_scl(-SH_C1 * y, dRGB));
+			b_st3(dsh, 2, b_scl(SH_C1 * z, dRGB));
+			b_st3(dsh, 3, b_scl(-SH_C1 * x, dRGB));
+			dx = b_scl(-SH_C1, b_ld3(sh, 3));
+			dy = b_scl(-SH_C1, b_ld3(sh, 1));
+			dz = b_scl(SH_C1, b_ld3(sh, 2));
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				b_st3(dsh, 4, b_scl(SH_C2[0] * xy, dRGB));
+				b_st3(dsh, 5, b_scl(SH_C2[1] * yz, dRGB));
+				b_st3(dsh, 6, b_scl(SH_C2[2] * (2.f * zz - xx - yy), dRGB));
+				b_st3(dsh, 7, b_scl(SH_C2[3] * xz, dRGB));
+				b_st3(dsh, 8, b_scl(SH_C2[4] * (xx - yy), dRGB));
+				const float3 s4 = b_ld3(sh, 4), s5 = b_ld3(sh, 5), s6 = b_ld3(sh, 6), s7 = b_ld3(sh, 7), s8 = b_ld3(sh, 8);
+				dx = b_add(dx, b_add(b_add(b_add(b_scl(SH_C2[0] * y, s4), b_scl(SH_C2[2] * 2.f * -x, s6)), b_scl(SH_C2[3] * z, s7)), b_scl(SH_C2[4] * 2.f * x, s8)));
+				dy = b_add(dy, b_add(b_add(b_add(b_scl(SH_C2[0] * x, s4), b_scl(SH_C2[1] * z, s5)), b_scl(SH_C2[2] * 2.f * -y, s6)), b_scl(SH_C2[4] * 2.f * -y, s8)));
+				dz = b_add(dz, b_add(b_add(b_scl(SH_C2[1] * y, s5), b_scl(SH_C2[2] * 2.f * 2.f * z, s6)), b_scl(SH_C2[3] * x, s7)));
+				if (deg > 2)
+				{
+					b_st3(dsh, 9, b_scl(SH_C3[0] * y * (3.f * xx - yy), dRGB));
+					b_st3(dsh, 10, b_scl(SH_C3[1] * xy * z, dRGB));
+					b_st3(dsh, 11, b_scl(SH_C3[2] * y * (4.f * zz - xx - yy), dRGB));
+					b_st3(dsh, 12, b_scl(SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), dRGB));
+					b_st3(dsh, 13, b_scl(SH_C3[4] * x * (4.f * zz - xx - yy), dRGB));
+					b_st3(dsh, 14, b_scl(SH_C3[5] * z * (xx - yy), dRGB));
+					b_st3(dsh, 15, b_scl(SH_C3[6] * x * (xx - 3.f * yy), dRGB));
+					const float3 s9 = b_ld3(sh, 9), s10 = b_ld3(sh, 10), s11 = b_ld3(sh, 11), s12 = b_ld3(sh, 12),
+					             s13 = b_ld3(sh, 13), s14 = b_ld3(sh, 14), s15 = b_ld3(sh, 15);
+					float3 ax = b_scl(SH_C3[0] * 3.f * 2.f * xy, s9);
+					ax = b_add(ax, b_scl(SH_C3[1] * yz, s10));
+					ax = b_add(ax, b_scl(SH_C3[2] * -2.f * xy, s11));
+					ax = b_add(ax, b_scl(SH_C3[3] * -3.f * 2.f * xz, s12));
+					ax = b_add(ax, b_scl(SH_C3[4] * (-3.f * xx + 4.f * zz - yy), s13));
+					ax = b_add(ax, b_scl(SH_C3[5] * 2.f * xz, s14));
+					ax = b_add(ax, b_scl(SH_C3[6] * 3.f * (xx - yy), s15));
+					dx = b_add(dx, ax);
+					float3 ay = b_scl(SH_C3[0] * 3.f * (xx - yy), s9);
+					ay = b_add(ay, b_scl(SH_C3[1] * xz, s10));
+					ay = b_add(ay, b_scl(SH_C3[2] * (-3.f * yy + 4.f * zz - xx), s11));
+					ay = b_add(ay, b_scl(SH_C3[3] * -3.f * 2.f * yz, s12));
+					ay = b_add(ay, b_scl(SH_C3[4] * -2.f * xy, s13));
+					ay = b_add(ay, b_scl(SH_C3[5] * -2.f * yz, s14));
+					ay = b_add(ay, b_scl(SH_C3[6] * -3.f * 2.f * xy, s15));
+					dy = b_add(dy, ay);
+					float3 az = b_scl(SH_C3[1] * xy, s10);
+					az = b_add(az, b_scl(SH_C3[2] * 4.f * 2.f * yz, s11));
+					az = b_add(az, b_scl(SH_C3[3] * 3.f * (2.f * zz - xx - yy), s12));
+					az = b_add(az, b_scl(SH_C3[4] * 4.f * 2.f * xz, s13));
+					az = b_add(az, b_scl(SH_C3[5] * (xx - yy), s14));
+					dz = b_add(dz, az);
+				}
+			}
+		}
+		return make_float3(b_dot(dx, dRGB), b_dot(dy, dRGB), b_dot(dz, dRGB));
+	}
+
+	// 4D SH backward (backward.cu:144-481), bug-compatible.  Returns dL/d(dir); *dL_dt receives the ts gradient.
+	__device__ float3 sh_bwd_4d(int deg, int deg_t, const float* __restrict__ sh, float* __restrict__ dsh, float3 dir, float3 dRGB,
+	                            float dir_t, float time_duration, float* dL_dt)
+	{
+		const float x = dir.x, y = dir.y, z = dir.z;
+		float l[16], dX[16], dY[16], dZ[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) { l[k] = 0.f; dX[k] = 0.f; dY[k] = 0.f; dZ[k] = 0.f; }
+		l[0] = SH_C0;
+		float3 gx = make_float3(0, 0, 0), gy = gx, gz = gx, gt = gx;
+		b_st3(dsh, 0, b_scl(l[0], dRGB));
+		if (deg > 0)
+		{
+			l[1] = -1 * SH_C1 * y; l[2] = SH_C1 * z; l[3] = -1 * SH_C1 * x;
+			dY[1] = -1 * SH_C1; dZ[2] = SH_C1; dX[3] = -1 * SH_C1;
+			b_st3(dsh, 1, b_scl(l[0], dRGB)); // Q1
+			b_st3(dsh, 2, b_scl(l[2], dRGB));
+			b_st3(dsh, 3, b_scl(l[3], dRGB));
+			gx = b_scl(dX[3], b_ld3(sh, 3));
+			gy = b_scl(dY[1], b_ld3(sh, 1));
+			gz = b_scl(dZ[2], b_ld3(sh, 2));
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				l[4] = SH_C2[0] * xy; l[5] = SH_C2[1] * yz; l[6] = (float)(SH_C2[2] * (2.0 * zz - xx - yy));
+				l[7] = SH_C2[3] * xz; l[8] = SH_C2[4] * (xx - yy);
+				dX[4] = SH_C2[0] * y; dY[4] = SH_C2[0] * x;
+				dY[5] = SH_C2[1] * z; dZ[5] = SH_C2[1] * y;
+				dX[6] = -2 * SH_C2[2] * x; dY[6] = -2 * SH_C2[2] * y; dZ[6] = 4 * SH_C2[2] * z;
+				dX[7] = SH_C2[3] * z; dZ[7] = SH_C2[3] * x;
+				dX[8] = 2 * SH_C2[4] * x; dY[8] = -2 * SH_C2[4] * y;
+				for (int k = 4; k <= 8; k++) b_st3(dsh, k, b_scl(l[k], dRGB));
+				const float3 s4 = b_ld3(sh, 4), s5 = b_ld3(sh, 5), s6 = b_ld3(sh, 6), s7 = b_ld3(sh, 7), s8 = b_ld3(sh, 8);
+				gx = b_add(gx, b_add(b_add(b_add(b_scl(dX[4], s4), b_scl(dX[6], s6)), b_scl(dX[7], s7)), b_scl(dX[8], s8)));
+				gy = b_add(gy, b_add(b_add(b_add(b_scl(dY[4], s4), b_scl(dY[5], s5)), b_scl(dY[6], s6)), b_scl(dY[8], s8)));
+				gz = b_add(gz, b_add(b_add(b_scl(dZ[5], s5), b_scl(dZ[6], s6)), b_scl(dZ[7], s7)));
+				if (deg > 2)
+				{
+					l[9] = SH_C3[0] * y * (3 * xx - yy);
+					l[10] = SH_C3[1] * xy * z;
+					l[11] = SH_C3[2] * y * (4 * zz - xx - yy);
+					l[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+					l[13] = SH_C3[4] * x * (4 * zz - xx - yy);
+					l[14] = SH_C3[5] * z * (xx - yy);
+					l[15] = SH_C3[6] * x * (xx - 3 * yy);
+					dX[9] = SH_C3[0] * y * 6 * x;               dY[9] = SH_C3[0] * (3 * xx - 3 * yy);
+					dX[10] = SH_C3[1] * yz;                     dY[10] = SH_C3[1] * xz;                     dZ[10] = SH_C3[1] * xy;
+					dX[11] = -SH_C3[2] * y * 2 * x;             dY[11] = SH_C3[2] * (4 * zz - xx - 3 * yy);  dZ[11] = SH_C3[2] * y * 8 * z;
+					dX[12] = -SH_C3[3] * z * 6 * x;             dY[12] = -SH_C3[3] * z * 6 * y;             dZ[12] = SH_C3[3] * (6 * zz - 3 * xx - 3 * yy);
+					dX[13] = SH_C3[4] * (4 * zz - 3 * xx - yy);  dY[13] = -SH_C3[4] * x * 2 * y;             dZ[13] = SH_C3[4] * x * 8 * z;
+					dX[14] = SH_C3[5] * z * 2 * x;              dY[14] = -SH_C3[5] * z * 2 * y;             dZ[14] = SH_C3[5] * (xx - yy);
+					dX[15] = SH_C3[6] * (3 * xx - 3 * yy);      dY[15] = -SH_C3[6] * x * 6 * y;
+					for (int k = 9; k <= 15; k++) b_st3(dsh, k, b_scl(l[k], dRGB));
+					float3 ax = b_scl(dX[9], b_ld3(sh, 9)), ay = b_scl(dY[9], b_ld3(sh, 9)), az = b_scl(dZ[10], b_ld3(sh, 10));
+					for (int k = 10; k <= 15; k++) { const float3 s = b_ld3(sh, k); ax = b_add(ax, b_scl(dX[k], s)); ay = b_add(ay, b_scl(dY[k], s)); }
+					for (int k = 11; k <= 14; k++) az = b_add(az, b_scl(dZ[k], b_ld3(sh, k)));
+					gx = b_add(gx, ax); gy = b_add(gy, ay); gz = b_add(gz, az);
+
+					for (int lev = 1; lev <= 2 && lev <= deg_t; lev++)
+					{
+						const int off = 16 * lev;
+						float tk, dtk_dt;
+						if (lev == 1)
+						{
+							tk = (float)cos(2 * REF_PI * dir_t / time_duration);
+							dtk_dt = (float)(sin(2 * REF_PI * dir_t / time_duration) * 2 * REF_PI / time_duration); // Q2
+						}
+						else
+						{
+							tk = (float)cos(2 * REF_PI * dir_t * 2 / time_duration);
+							dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / time_duration) * 2 * REF_PI * 2 / time_duration);
+						}
+						float3 st = make_float3(0, 0, 0), sx = st, sy = st, sz = st;
+						for (int k = 0; k < 16; k++)
+						{
+							const float3 s = b_ld3(sh, off + k);
+							b_st3(dsh, off + k, b_scl(tk * l[k], dRGB));
+							st = b_add(st, b_scl(l[k], s));
+							// terms the reference omits have a zero derivative entry (dX/dY/dZ == 0), e.g. dX[1], dX[2], dX[5]
+							sx = b_add(sx, b_scl(dX[k], s));
+							sy = b_add(sy, b_scl(dY[k], s));
+							sz = b_add(sz, b_scl(dZ[k], s));
+						}
+						gt = b_scl(dtk_dt, st); // Q3: overwrite, not accumulate
+						gx = b_add(gx, b_scl(tk, sx));
+						gy = b_add(gy, b_scl(tk, sy));
+						gz = b_add(gz, b_scl(tk, sz));
+					}
+				}
+			}
+		}
+		*dL_dt = b_dot(gt, dRGB);
+		return make_float3(b_dot(gx, dRGB), b_dot(gy, dRGB), b_dot(gz, dRGB));
+	}
+
+	__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const BwdArgs a)
+	{
+		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= a.P) return;
+		const bool visible = a.radii[idx] > 0; // backward.cu:499, 873-875
+
+		float3 dmean = make_float3(0, 0, 0);
+		float dcov[6] = { 0, 0, 0, 0, 0, 0 };
+		float dts = 0.f;
+		float3 dscale = make_float3(0, 0, 0);
+		float dscale_t = 0.f;
+		float4 drot = make_float4(0, 0, 0, 0), drot_r = make_float4(0, 0, 0, 0);
+		const int n_sh_floats = a.shs ? a.M * 3 : 0;
+		float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * n_sh_floats : nullptr;
+
+		if (!visible)
+		{
+			for (int k = 0; k < n_sh_floats; k++) dsh[k] = 0.f;
+		}
+		else
+		{
+			const float3 mean = b_ld3(a.means, idx);
+			const float* cov3D = (a.cov3D_precomp ? a.cov3D_precomp : a.cov3D) + 6 * (size_t)idx;
+			float c3[6];
+#pragma unroll
+			for (int k = 0; k < 6; k++) c3[k] = cov3D[k];
+
+			// ---------------- cov2D backward (backward.cu:486-617) ----------------
+			{
+				const float4 dcon = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
+				const float dcx = dcon.x, dcy = dcon.y, dcz = dcon.w;
+				const Cov2D p = project_cov(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.viewmatrix);
+				const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+				const float x_grad_mul = (p.txtz < -limx || p.txtz > limx) ? 0.f : 1.f;
+				const float y_grad_mul = (p.tytz < -limy || p.tytz > limy) ? 0.f : 1.f;
+				const float ca = p.a + 0.3f, cb = p.b, cc = p.c + 0.3f;
+				const float denom = ca * cc - cb * cb;
+				float dL_da = 0, dL_db = 0, dL_dc = 0;
+				const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define TT(i, j) p.T.c[i][j]
+#define VV(i, j) p.Vrk.c[i][j]
+#define WW(i, j) p.W.c[i][j]
+				if (denom2inv != 0)
+				{
+					dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+					dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+					dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+					dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+					dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+					dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+					dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+					dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+					dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+				}
+				const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+				const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+				const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da + (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+				const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc + (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+				const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc + (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+				const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc + (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+				const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+				const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+				const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+				const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+#undef TT
+#undef VV
+#undef WW
+				const float tz = 1.f / p.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+				const float h_x = a.focal_x, h_y = a.focal_y;
+				const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+				const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+				const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * p.t.x) * tz3 * dL_dJ02 + (2 * h_y * p.t.y) * tz3 * dL_dJ12;
+				const float vz = dL_dtz + a.dL_dmean2D[3 * (size_t)idx + 2]; // Q10: depth-gradient carrier
+				const float* m = a.viewmatrix; // transformVec4x3Transpose, auxiliary.h:90-98
+				dmean.x = m[0] * dL_dtx + m[1] * dL_dty + m[2] * vz;
+				dmean.y = m[4] * dL_dtx + m[5] * dL_dty + m[6] * vz;
+				dmean.z = m[8] * dL_dtx + m[9] * dL_dty + m[10] * vz;
+			}
+
+			// ---------------- projection (backward.cu:877-894) ----------------
+			{
+				const float* proj = a.projmatrix;
+				const float4 m_hom = xform4x4(mean, proj);
+				const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+				const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+				const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+				const float gx = a.dL_dmean2D[3 * (size_t)idx], gy = a.dL_dmean2D[3 * (size_t)idx + 1];
+				dmean.x += (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
+				dmean.y += (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
+				dmean.z += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
+			}
+
+			// ---------------- SH (backward.cu:897-906) ----------------
+			if (a.shs)
+			{
+				const float3 campos = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+				const float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z); // Q4
+				const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+				const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+				float3 dRGB = b_ld3(a.dL_dcolor, idx);
+				const uint8_t cl = a.clamped[idx];
+				if (cl & 1) dRGB.x = 0.f;
+				if (cl & 2) dRGB.y = 0.f;
+				if (cl & 4) dRGB.z = 0.f;
+				const float* sh = a.shs + (size_t)idx * n_sh_floats;
+				float3 ddir;
+				int written;
+				if (a.gaussian_dim == 3 || a.force_sh_3d)
+				{
+					ddir = sh_bwd_3d(a.D, sh, dsh, dir, dRGB);
+					written = (a.D + 1) * (a.D + 1);
+				}
+				else
+				{
+					float dt_sh = 0.f;
+					ddir = sh_bwd_4d(a.D, a.D_t, sh, dsh, dir, dRGB, a.ts[idx] - a.timestamp, a.time_duration, &dt_sh);
+					dts += dt_sh;
+					written = (a.D + 1) * (a.D + 1);
+					if (a.D > 2) written = 16 * (1 + min(max(a.D_t, 0), 2));
+				}
+				for (int k = written * 3; k < n_sh_floats; k++) dsh[k] = 0.f; // coefficients above the active degree
+				const float3 dm = dnormvdv(dir_orig, ddir);
+				dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
+			}
+
+			// ---------------- covariance (backward.cu:907-922) ----------------
+			if (a.scales)
+			{
+				const float mod = a.scale_modifier;
+				const float3 sc = b_ld3(a.scales, idx);
+				if (a.rot_4d)
+				{
+					// backward.cu:689-834
+					const float scale_t = a.scales_t[idx];
+					const float dt = a.timestamp - a.ts[idx];
+					const M4 S = diag4(mod * sc.x, mod * sc.y, mod * sc.z, mod * scale_t);
+					M4 Ml, Mr;
+					build_Ml_Mr(reinterpret_cast<const float4*>(a.rotations)[idx], reinterpret_cast<const float4*>(a.rotations_r)[idx], Ml, Mr);
+					const M4 R = mul(Mr, Ml);
+					const M4 M = mul(S, R);
+					const M4 Sigma = mul(transpose(M), M);
+					const float cov_t = Sigma.c[3][3];
+					const float cov_t_pre = (a.prefilter_var > 0.0) ? (a.prefilter_var + cov_t) : cov_t;
+					const float marginal_t = expf((float)(-0.5 * dt * dt / cov_t_pre));
+					if (marginal_t > 0.05)
+					{
+						const float c12[3] = { Sigma.c[3][0], Sigma.c[3][1], Sigma.c[3][2] }; // Q7
+						float d12[3];
+						d12[0] = -(float)(dcov[0] * c12[0] + dcov[1] * c12[1] * 0.5 + dcov[2] * c12[2] * 0.5) * 2.0f / cov_t;
+						d12[1] = -(float)(dcov[1] * c12[0] * 0.5 + dcov[3] * c12[1] + dcov[4] * c12[2] * 0.5) * 2.0f / cov_t;
+						d12[2] = -(float)(dcov[2] * c12[0] * 0.5 + dcov[4] * c12[1] * 0.5 + dcov[5] * c12[2]) * 2.0f / cov_t;
+						float dL_dcovt = (c12[0] * c12[0] * dcov[0] + c12[0] * c12[1] * dcov[1] +
+						                  c12[0] * c12[2] * dcov[2] + c12[1] * c12[1] * dcov[3] +
+						                  c12[1] * c12[2] * dcov[4] + c12[2] * c12[2] * dcov[5]) / (cov_t * cov_t);
+						const float dop = a.dL_dopacity[idx];
+						const float dL_dmarginal_t = dop * a.opacities[idx];
+						a.dL_dopacity[idx] = dop * marginal_t;
+						const float dmarg_dcovt = marginal_t * dt * dt / 2 / (cov_t_pre * cov_t_pre);
+						const float dmarg_dt = marginal_t * dt / cov_t_pre;
+						dL_dcovt += dmarg_dcovt * dL_dmarginal_t;
+						float dL_dt = dL_dmarginal_t * dmarg_dt;
+						// Q5: the whole mean gradient is treated as the gradient of delta_mean
+						d12[0] += dmean.x / cov_t * dt; d12[1] += dmean.y / cov_t * dt; d12[2] += dmean.z / cov_t * dt;
+						const float ddot = dmean.x * c12[0] + dmean.y * c12[1] + dmean.z * c12[2];
+						dL_dcovt += -ddot / (cov_t * cov_t) * dt;
+						dL_dt += -ddot / cov_t;
+						dts += dL_dt;
+						M4 dSig;
+						dSig.c[0][0] = dcov[0]; dSig.c[0][1] = 0.5f * dcov[1]; dSig.c[0][2] = 0.5f * dcov[2]; dSig.c[0][3] = 0.5f * d12[0];
+						dSig.c[1][0] = 0.5f * dcov[1]; dSig.c[1][1] = dcov[3]; dSig.c[1][2] = 0.5f * dcov[4]; dSig.c[1][3] = 0.5f * d12[1];
+						dSig.c[2][0] = 0.5f * dcov[2]; dSig.c[2][1] = 0.5f * dcov[4]; dSig.c[2][2] = dcov[5]; dSig.c[2][3] = 0.5f * d12[2];
+						dSig.c[3][0] = 0.5f * d12[0]; dSig.c[3][1] = 0.5f * d12[1]; dSig.c[3][2] = 0.5f * d12[2]; dSig.c[3][3] = dL_dcovt;
+						M4 M2;
+#pragma unroll
+						for (int j = 0; j < 4; j++)
+#pragma unroll
+							for (int i = 0; i < 4; i++) M2.c[j][i] = 2.0f * M.c[j][i];
+						const M4 dM = mul(M2, dSig);
+						const M4 Rt = transpose(R);
+						M4 dMt = transpose(dM);
+						dscale.x = dot4(Rt.c[0], dMt.c[0]);
+						dscale.y = dot4(Rt.c[1], dMt.c[1]);
+						dscale.z = dot4(Rt.c[2], dMt.c[2]);
+						dscale_t = dot4(Rt.c[3], dMt.c[3]);
+						const float scl[4] = { mod * sc.x, mod * sc.y, mod * sc.z, mod * scale_t };
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+#pragma unroll
+							for (int i = 0; i < 4; i++) dMt.c[k][i] *= scl[k];
+						const M4 A = mul(dMt, Mr);
+						drot.x = A.c[0][0] + A.c[1][1] + A.c[2][2] + A.c[3][3];
+						drot.y = -A.c[0][1] + A.c[1][0] - A.c[2][3] + A.c[3][2];
+						drot.z = A.c[0][2] - A.c[1][3] - A.c[2][0] + A.c[3][1];
+						drot.w = -A.c[0][3] - A.c[1][2] + A.c[2][1] + A.c[3][0];
+						const M4 B = mul(Ml, dMt);
+						drot_r.x = B.c[0][0] + B.c[1][1] + B.c[2][2] + B.c[3][3];
+						drot_r.y = -B.c[0][1] + B.c[1][0] + B.c[2][3] - B.c[3][2];
+						drot_r.z = B.c[0][2] + B.c[1][3] - B.c[2][0] - B.c[3][1];
+						drot_r.w = B.c[0][3] - B.c[1][2] + B.c[2][1] - B.c[3][0];
+					}
+				}
+				else
+				{
+					// backward.cu:621-684
+					const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+					const float r = q.x, x = q.y, y = q.z, z = q.w;
+					const M3 R = quat_to_R(q);
+					const float s3[3] = { mod * sc.x, mod * sc.y, mod * sc.z };
+					M3 S;
+#pragma unroll
+					for (int j = 0; j < 3; j++)
+#pragma unroll
+						for (int i = 0; i < 3; i++) S.c[j][i] = 0.f;
+					S.c[0][0] = s3[0]; S.c[1][1] = s3[1]; S.c[2][2] = s3[2];
+					const M3 M = mul(S, R);
+					M3 dSig;
+					dSig.c[0][0] = dcov[0]; dSig.c[0][1] = 0.5f * dcov[1]; dSig.c[0][2] = 0.5f * dcov[2];
+					dSig.c[1][0] = 0.5f * dcov[1]; dSig.c[1][1] = dcov[3]; dSig.c[1][2] = 0.5f * dcov[4];
+					dSig.c[2][0] = 0.5f * dcov[2]; dSig.c[2][1] = 0.5f * dcov[4]; dSig.c[2][2] = dcov[5];
+					M3 M2;
+#pragma unroll
+					for (int j = 0; j < 3; j++)
+#pragma unroll
+						for (int i = 0; i < 3; i++) M2.c[j][i] = 2.0f * M.c[j][i];
+					const M3 dM = mul(M2, dSig);
+					const M3 Rt = transpose(R);
+					M3 dMt = transpose(dM);
+					dscale.x = dot3(Rt.c[0][0], Rt.c[0][1], Rt.c[0][2], dMt.c[0][0], dMt.c[0][1], dMt.c[0][2]);
+					dscale.y = dot3(Rt.c[1][0], Rt.c[1][1], Rt.c[1][2], dMt.c[1][0], dMt.c[1][1], dMt.c[1][2]);
+					dscale.z = dot3(Rt.c[2][0], Rt.c[2][1], Rt.c[2][2], dMt.c[2][0], dMt.c[2][1], dMt.c[2][2]);
+#pragma unroll
+					for (int k = 0; k < 3; k++)
+#pragma unroll
+						for (int i = 0; i < 3; i++) dMt.c[k][i] *= s3[k];
+#define DD(i, j) dMt.c[i][j]
+					drot.x = 2 * z * (DD(0, 1) - DD(1, 0)) + 2 * y * (DD(2, 0) - DD(0, 2)) + 2 * x * (DD(1, 2) - DD(2, 1));
+					drot.y = 2 * y * (DD(1, 0) + DD(0, 1)) + 2 * z * (DD(2, 0) + DD(0, 2)) + 2 * r * (DD(1, 2) - DD(2, 1)) - 4 * x * (DD(2, 2) + DD(1, 1));
+					drot.z = 2 * x * (DD(1, 0) + DD(0, 1)) + 2 * r * (DD(2, 0) - DD(0, 2)) + 2 * z * (DD(1, 2) + DD(2, 1)) - 4 * y * (DD(2, 2) + DD(0, 0));
+					drot.w = 2 * r * (DD(0, 1) - DD(1, 0)) + 2 * x * (DD(2, 0) + DD(0, 2)) + 2 * y * (DD(1, 2) + DD(2, 1)) - 4 * z * (DD(1, 1) + DD(0, 0));
+#undef DD
+					// Q6: gaussian_dim == 4 without rot_4d has no marginal-opacity backward
+				}
+			}
+		}
+
+		// ---- stores (every output written for every Gaussian) ----
+		b_st3(a.dL_dmeans, idx, dmean);
+#pragma unroll
+		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+		if (a.dL_dts) a.dL_dts[idx] = dts;
+		if (a.dL_dscale) b_st3(a.dL_dscale, idx, dscale);
+		if (a.dL_dscale_t) a.dL_dscale_t[idx] = dscale_t;
+		if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+		if (a.dL_drot_r) reinterpret_cast<float4*>(a.dL_drot_r)[idx] = drot_r;
+	}
+
+	hipError_t launch_preprocess_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
+	                                 const char* geom, hipStream_t stream)
+	{
+		const GeomLayout L = geom_layout(s.P);
+		BwdArgs a;
+		a.P = s.P; a.D = s.D; a.D_t = s.D_t; a.M = s.M;
+		a.shs = s.shs; a.opacities = s.opacities; a.ts = s.ts; a.scales = s.scales; a.scales_t = s.scales_t;
+		a.rotations = s.rotations; a.rotations_r = s.rotations_r; a.cov3D_precomp = s.cov3D_precomp;
+		a.viewmatrix = s.viewmatrix; a.projmatrix = s.projmatrix; a.campos = s.campos;
+		a.scale_modifier = s.scale_modifier; a.prefilter_var = s.prefilter_var;
+		a.tan_fovx = s.tan_fovx; a.tan_fovy = s.tan_fovy;
+		a.focal_y = s.H / (2.0f * s.tan_fovy); // rasterizer_impl.cu:424-425
+		a.focal_x = s.W / (2.0f * s.tan_fovx);
+		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
+		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+		a.radii = in.radii; a.means = in.out_means3D;
+		a.cov3D = reinterpret_cast<const float*>(geom + L.cov3D);
+		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
+		a.dL_dmean2D = out.dL_dmeans2D; a.dL_dconic = out.dL_dconic; a.dL_dcolor = out.dL_dcolors;
+		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
+		a.dL_dsh = s.shs ? out.dL_dsh : nullptr;
+		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;
+		a.dL_drot = out.dL_drotations; a.dL_drot_r = out.dL_drotations_r;
+		hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		return hipGetLastError();
+	}
+}

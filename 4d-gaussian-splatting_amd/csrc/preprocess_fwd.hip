@@ -1,0 +1,350 @@
+// preprocess_fwd.hip -- per-Gaussian forward preprocessing for gfx950.
+//
+// What it computes (reference preprocessCUDA, forward.cu:355-496): 4D -> 3D
+// conditional covariance + conditional mean shift + temporal marginal opacity
+// (forward.cu:279-352) or 3D covariance with the 1-D temporal marginal
+// (forward.cu:242-276, 431-437), near cull (auxiliary.h:140-163), EWA projection
+// (forward.cu:198-237), conic, radius, tile rectangle (auxiliary.h:47-57),
+// SH / 4D-SH -> RGB (forward.cu:20-195).
+//
+// What is different from the reference's kernel: it emits ONE packed 48-byte
+// blend record per Gaussian (position, conic, opacity, colour, depth, flow)
+// instead of four separate arrays, the tile rectangle (so later stages never
+// recompute it), the depth-sort key/value pair, and it writes every output
+// unconditionally so no buffer needs pre-zeroing.
+//
+// Bit-exactness: radius, rectangle, tile count and depth bits must equal the
+// oracle's exactly, so this file is compiled with FP contraction OFF and follows
+// the evaluation order fixed in fdgs_math.h; double promotions of the
+// reference (ndc2Pix, the -0.5*dt*dt/var exponent, 2.0*zz, 2*pi*...) are kept.
+// FP contraction must be off for everything below, including the inline helpers of fdgs_math.h.
+#pragma clang fp contract(off)
+#include "fdgs_common.h"
+#include "fdgs_math.h"
+
+namespace fdgs
+{
+	struct PreArgs
+	{
+		int P, D, D_t, M, W, H;
+		const float *means3D, *shs, *colors_precomp, *flows, *opacities, *ts, *scales, *scales_t;
+		const float *rotations, *rotations_r, *cov3D_precomp, *viewmatrix, *projmatrix, *campos;
+		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
+		int rot_4d, gaussian_dim, force_sh_3d;
+		int grid_x, grid_y;
+		// outputs
+		int32_t* radii; float* out_means3D; float* covs_com;
+		float4* records; float* depths; float* cov3D; uint32_t* tiles_touched; ushort4* rect; uint8_t* clamped;
+		uint32_t* sort_key; uint32_t* sort_val;
+	};
+
+	__device__ __forceinline__ float3 ld3(const float* p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+	__device__ __forceinline__ float3 add3(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+	__device__ __forceinline__ float3 scl3(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
+	__device__ __forceinline__ float3 sub3(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+	// 3D SH (forward.cu:20-71); returns the un-clamped colour + 0.5
+	__device__ float3 sh_color_3d(int deg, const float* __restrict__ sh, float3 dir)
+	{
+		float3 result = scl3(SH_C0, ld3(sh, 0));
+		if (deg > 0)
+		{
+			const float x = dir.x, y = dir.y, z = dir.z;
+			result = sub3(add3(sub3(result, scl3(SH_C1 * y, ld3(sh, 1))), scl3(SH_C1 * z, ld3(sh, 2))), scl3(SH_C1 * x, ld3(sh, 3)));
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				result = add3(result, scl3(SH_C2[0] * xy, ld3(sh, 4)));
+				result = add3(result, scl3(SH_C2[1] * yz, ld3(sh, 5)));
+				result = add3(result, scl3(SH_C2[2] * (2.0f * zz - xx - yy), ld3(sh, 6)));
+				result = add3(result, scl3(SH_C2[3] * xz, ld3(sh, 7)));
+				result = add3(result, scl3(SH_C2[4] * (xx - yy), ld3(sh, 8)));
+				if (deg > 2)
+				{
+					result = add3(result, scl3(SH_C3[0] * y * (3.0f * xx - yy), ld3(sh, 9)));
+					result = add3(result, scl3(SH_C3[1] * xy * z, ld3(sh, 10)));
+					result = add3(result, scl3(SH_C3[2] * y * (4.0f * zz - xx - yy), ld3(sh, 11)));
+					result = add3(result, scl3(SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), ld3(sh, 12)));
+					result = add3(result, scl3(SH_C3[4] * x * (4.0f * zz - xx - yy), ld3(sh, 13)));
+					result = add3(result, scl3(SH_C3[5] * z * (xx - yy), ld3(sh, 14)));
+					result = add3(result, scl3(SH_C3[6] * x * (xx - 3.0f * yy), ld3(sh, 15)));
+				}
+			}
+		}
+		return make_float3(result.x + 0.5f, result.y + 0.5f, result.z + 0.5f);
+	}
+
+	// basis values of the 4D path (forward.cu:87-131; note the double promotion in l2m0)
+	__device__ __forceinline__ void sh_basis_4d(int deg, float x, float y, float z, float* l)
+	{
+		l[0] = SH_C0;
+		if (deg > 0)
+		{
+			l[1] = -1 * SH_C1 * y; l[2] = SH_C1 * z; l[3] = -1 * SH_C1 * x;
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				l[4] = SH_C2[0] * xy;
+				l[5] = SH_C2[1] * yz;
+				l[6] = (float)(SH_C2[2] * (2.0 * zz - xx - yy));
+				l[7] = SH_C2[3] * xz;
+				l[8] = SH_C2[4] * (xx - yy);
+				if (deg > 2)
+				{
+					l[9] = SH_C3[0] * y * (3 * xx - yy);
+					l[10] = SH_C3[1] * xy * z;
+					l[11] = SH_C3[2] * y * (4 * zz - xx - yy);
+					l[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+					l[13] = SH_C3[4] * x * (4 * zz - xx - yy);
+					l[14] = SH_C3[5] * z * (xx - yy);
+					l[15] = SH_C3[6] * x * (xx - 3 * yy);
+				}
+			}
+		}
+	}
+	__device__ __forceinline__ float3 sh_weighted(const float* l, const float* __restrict__ sh, int lo, int hi, int off)
+	{
+		float3 acc = scl3(l[lo - off], ld3(sh, lo));
+		for (int k = lo + 1; k <= hi; k++) acc = add3(acc, scl3(l[k - off], ld3(sh, k)));
+		return acc;
+	}
+	// 4D SH (forward.cu:73-195); time harmonics only when deg > 2
+	__device__ float3 sh_color_4d(int deg, int deg_t, const float* __restrict__ sh, float3 dir, float dir_t, float time_duration)
+	{
+		float l[16];
+		sh_basis_4d(deg, dir.x, dir.y, dir.z, l);
+		float3 result = scl3(l[0], ld3(sh, 0));
+		if (deg > 0)
+		{
+			result = add3(result, sh_weighted(l, sh, 1, 3, 0));
+			if (deg > 1)
+			{
+				result = add3(result, sh_weighted(l, sh, 4, 8, 0));
+				if (deg > 2)
+				{
+					result = add3(result, sh_weighted(l, sh, 9, 15, 0));
+					if (deg_t > 0)
+					{
+						const float t1 = (float)cos(2 * REF_PI * dir_t / time_duration);
+						result = add3(result, scl3(t1, sh_weighted(l, sh, 16, 31, 16)));
+						if (deg_t > 1)
+						{
+							const float t2 = (float)cos(2 * REF_PI * dir_t * 2 / time_duration);
+							result = add3(result, scl3(t2, sh_weighted(l, sh, 32, 47, 32)));
+						}
+					}
+				}
+			}
+		}
+		return make_float3(result.x + 0.5f, result.y + 0.5f, result.z + 0.5f);
+	}
+
+	__global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreArgs a)
+	{
+		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= a.P) return;
+
+		float3 p_orig = ld3(a.means3D, idx);
+		const float3 p_in = p_orig;
+		float opacity = a.opacities[idx];
+		float cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+		bool alive = true;
+
+		if (a.cov3D_precomp != nullptr)
+		{
+#pragma unroll
+			for (int k = 0; k < 6; k++) cov[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+		}
+		else if (a.rot_4d)
+		{
+			// forward.cu:279-352
+			const float3 sc = ld3(a.scales, idx);
+			const float mod = a.scale_modifier;
+			const float dt = a.timestamp - a.ts[idx];
+			const M4 S = diag4(mod * sc.x, mod * sc.y, mod * sc.z, mod * a.scales_t[idx]);
+			M4 Ml, Mr;
+			build_Ml_Mr(reinterpret_cast<const float4*>(a.rotations)[idx], reinterpret_cast<const float4*>(a.rotations_r)[idx], Ml, Mr);
+			const M4 M = mul(S, mul(Mr, Ml));
+			const M4 Sigma = mul(transpose(M), M);
+			const float cov_t = Sigma.c[3][3];
+			const float marginal_t = expf((float)(-0.5 * dt * dt / ((a.prefilter_var > 0.0) ? (a.prefilter_var + cov_t) : cov_t)));
+			alive = marginal_t > 0.05;
+			if (alive)
+			{
+				opacity *= marginal_t;
+				const float c12[3] = { Sigma.c[0][3], Sigma.c[1][3], Sigma.c[2][3] };
+				cov[0] = Sigma.c[0][0] - (c12[0] * c12[0]) / cov_t;
+				cov[1] = Sigma.c[0][1] - (c12[1] * c12[0]) / cov_t;
+				cov[2] = Sigma.c[0][2] - (c12[2] * c12[0]) / cov_t;
+				cov[3] = Sigma.c[1][1] - (c12[1] * c12[1]) / cov_t;
+				cov[4] = Sigma.c[1][2] - (c12[2] * c12[1]) / cov_t;
+				cov[5] = Sigma.c[2][2] - (c12[2] * c12[2]) / cov_t;
+				p_orig.x += c12[0] / cov_t * dt;
+				p_orig.y += c12[1] / cov_t * dt;
+				p_orig.z += c12[2] / cov_t * dt;
+			}
+		}
+		else
+		{
+			// forward.cu:242-276
+			const float3 sc = ld3(a.scales, idx);
+			const float mod = a.scale_modifier;
+			M3 S;
+#pragma unroll
+			for (int j = 0; j < 3; j++)
+#pragma unroll
+				for (int i = 0; i < 3; i++) S.c[j][i] = 0.0f;
+			S.c[0][0] = mod * sc.x; S.c[1][1] = mod * sc.y; S.c[2][2] = mod * sc.z;
+			const M3 M = mul(S, quat_to_R(reinterpret_cast<const float4*>(a.rotations)[idx]));
+			const M3 Sigma = mul(transpose(M), M);
+			cov[0] = Sigma.c[0][0]; cov[1] = Sigma.c[0][1]; cov[2] = Sigma.c[0][2];
+			cov[3] = Sigma.c[1][1]; cov[4] = Sigma.c[1][2]; cov[5] = Sigma.c[2][2];
+			if (a.gaussian_dim == 4)
+			{
+				// forward.cu:431-437 (scales_t used as a variance)
+				const float dt = a.ts[idx] - a.timestamp;
+				const float sigma = a.scales_t[idx] * mod;
+				const float marginal_t = expf((float)(-0.5 * dt * dt / ((a.prefilter_var > 0.0) ? (a.prefilter_var + sigma) : sigma)));
+				if (marginal_t <= 0.05) alive = false;
+				else opacity *= marginal_t;
+			}
+		}
+
+		int radius = 0;
+		uint32_t tiles = 0;
+		ushort4 rect = make_ushort4(0, 0, 0, 0);
+		float depth = 0.0f;
+		float2 pix = make_float2(0.f, 0.f);
+		float3 conic = make_float3(0.f, 0.f, 0.f);
+		float3 rgb = make_float3(0.f, 0.f, 0.f);
+		uint8_t clampbits = 0;
+
+		if (alive)
+		{
+			const float3 p_view = xform4x3(p_orig, a.viewmatrix);
+			alive = !(p_view.z <= 0.2f); // auxiliary.h:153
+			if (alive)
+			{
+				const float4 p_hom = xform4x4(p_orig, a.projmatrix);
+				const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+				const float p_proj_x = p_hom.x * p_w, p_proj_y = p_hom.y * p_w;
+				const Cov2D c2 = project_cov(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov, a.viewmatrix);
+				const float cx = c2.a + 0.3f, cy = c2.b, cz = c2.c + 0.3f;
+				const float det = (cx * cz - cy * cy);
+				if (det == 0.0f) alive = false;
+				else
+				{
+					const float det_inv = 1.f / det;
+					conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+					const float mid = 0.5f * (cx + cz);
+					const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+					const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+					const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+					// auxiliary.h:42-45 (double)
+					pix.x = (float)(((p_proj_x + 1.0) * a.W - 1.0) * 0.5);
+					pix.y = (float)(((p_proj_y + 1.0) * a.H - 1.0) * 0.5);
+					// auxiliary.h:47-57
+					const int r = (int)my_radius;
+					const int x0 = min(a.grid_x, max(0, (int)((pix.x - r) / TILE_X)));
+					const int y0 = min(a.grid_y, max(0, (int)((pix.y - r) / TILE_Y)));
+					const int x1 = min(a.grid_x, max(0, (int)((pix.x + r + TILE_X - 1) / TILE_X)));
+					const int y1 = min(a.grid_y, max(0, (int)((pix.y + r + TILE_Y - 1) / TILE_Y)));
+					if ((x1 - x0) * (y1 - y0) == 0 || r <= 0) alive = false; // forward.cu:471
+					else
+					{
+						radius = r;
+						tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+						rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+						depth = p_view.z;
+					}
+				}
+			}
+		}
+
+		if (alive)
+		{
+			if (a.colors_precomp != nullptr) rgb = ld3(a.colors_precomp, idx);
+			else
+			{
+				// Q4: the forward view direction uses the UN-shifted input mean (forward.cu:480-482)
+				float3 dir = sub3(p_in, make_float3(a.campos[0], a.campos[1], a.campos[2]));
+				const float len = sqrtf(dot3(dir.x, dir.y, dir.z, dir.x, dir.y, dir.z));
+				dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+				const float* sh = a.shs + (size_t)idx * a.M * 3;
+				float3 c;
+				if (a.gaussian_dim == 3 || a.force_sh_3d) c = sh_color_3d(a.D, sh, dir);
+				else c = sh_color_4d(a.D, a.D_t, sh, dir, a.ts[idx] - a.timestamp, a.time_duration);
+				clampbits = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
+				rgb = make_float3(fmaxf(c.x, 0.0f), fmaxf(c.y, 0.0f), fmaxf(c.z, 0.0f));
+			}
+		}
+
+		// ---- stores (every output written for every Gaussian) ----
+		a.radii[idx] = radius;
+		a.tiles_touched[idx] = tiles;
+		a.rect[idx] = rect;
+		a.depths[idx] = depth;
+		a.clamped[idx] = clampbits;
+		a.out_means3D[3 * (size_t)idx + 0] = p_orig.x;
+		a.out_means3D[3 * (size_t)idx + 1] = p_orig.y;
+		a.out_means3D[3 * (size_t)idx + 2] = p_orig.z;
+#pragma unroll
+		for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = cov[k];
+		if (a.covs_com != nullptr)
+		{
+#pragma unroll
+			for (int k = 0; k < 6; k++) a.covs_com[6 * (size_t)idx + k] = cov[k];
+		}
+		float2 flow = make_float2(0.f, 0.f);
+		if (a.flows != nullptr) flow = reinterpret_cast<const float2*>(a.flows)[idx];
+		a.records[3 * (size_t)idx + 0] = make_float4(pix.x, pix.y, conic.x, conic.y);
+		a.records[3 * (size_t)idx + 1] = make_float4(conic.z, radius > 0 ? opacity : 0.0f, rgb.x, rgb.y);
+		a.records[3 * (size_t)idx + 2] = make_float4(rgb.z, depth, flow.x, flow.y);
+		// depth-sort pair: culled Gaussians sort to the end and emit no instances
+		a.sort_key[idx] = radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu;
+		a.sort_val[idx] = (uint32_t)idx;
+	}
+
+	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, hipStream_t stream)
+	{
+		const GeomLayout L = geom_layout(s.P);
+		PreArgs a;
+		a.P = s.P; a.D = s.D; a.D_t = s.D_t; a.M = s.M; a.W = s.W; a.H = s.H;
+		a.means3D = s.means3D; a.shs = s.shs; a.colors_precomp = s.colors_precomp; a.flows = s.flows;
+		a.opacities = s.opacities; a.ts = s.ts; a.scales = s.scales; a.scales_t = s.scales_t;
+		a.rotations = s.rotations; a.rotations_r = s.rotations_r; a.cov3D_precomp = s.cov3D_precomp;
+		a.viewmatrix = s.viewmatrix; a.projmatrix = s.projmatrix; a.campos = s.campos;
+		a.scale_modifier = s.scale_modifier; a.prefilter_var = s.prefilter_var;
+		a.tan_fovx = s.tan_fovx; a.tan_fovy = s.tan_fovy;
+		a.focal_y = s.H / (2.0f * s.tan_fovy); // rasterizer_impl.cu:235-236
+		a.focal_x = s.W / (2.0f * s.tan_fovx);
+		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
+		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+		a.grid_x = div_up(s.W, TILE_X); a.grid_y = div_up(s.H, TILE_Y);
+		a.radii = out.radii; a.out_means3D = out.out_means3D; a.covs_com = out.covs_com;
+		a.records = reinterpret_cast<float4*>(geom + L.records);
+		a.depths = reinterpret_cast<float*>(geom + L.depths);
+		a.cov3D = reinterpret_cast<float*>(geom + L.cov3D);
+		a.tiles_touched = reinterpret_cast<uint32_t*>(geom + L.tiles_touched);
+		a.rect = reinterpret_cast<ushort4*>(geom + L.rect);
+		a.clamped = reinterpret_cast<uint8_t*>(geom + L.clamped);
+		a.sort_key = reinterpret_cast<uint32_t*>(geom + L.sort_key[0]);
+		a.sort_val = reinterpret_cast<uint32_t*>(geom + L.sort_val[0]);
+		hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		return hipGetLastError();
+	}
+
+	// checkFrustum (rasterizer_impl.cu:54-67)
+	__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm, uint8_t* present)
+	{
+		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= P) return;
+		const float3 pv = xform4x3(ld3(means3D, idx), vm);
+		present[idx] = !(pv.z <= 0.2f);
+	}
+	hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream)
+	{
+		hipLaunchKernelGGL(mark_visible_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+		return hipGetLastError();
+	}
+}

@@ -1,0 +1,311 @@
+"""Drop-in for the reference module ``gaussian_renderer.diff_gaussian_rasterization``.
+
+Same public surface (gaussian_renderer/diff_gaussian_rasterization.py in the
+reference): ``GaussianRasterizationSettings`` (:227-245), ``GaussianRasterizer``
+(:247-318, ``forward`` and ``markVisible``), ``rasterize_gaussians`` (:34-65) and
+the autograd function ``_RasterizeGaussians`` (:67-225) -- same argument
+orders, defaults, output order / shapes / dtypes and exceptions.  The reference
+JIT-compiles and calls a CUDA pybind module ``_C``; here ``_C`` is a small object
+with the same three entry points (ext.cpp:15-19) that forwards raw device
+pointers to the hand-written HIP kernels in ``csrc/libfdgs.so`` through the C
+ABI of ``include/fdgs.h``.  No rasterization arithmetic happens in Python and
+there is no CPU fallback.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from .. import _capi
+
+
+def _is_given(t) -> bool:
+    return t is not None and t.numel() > 0
+
+
+class _Scratch:
+    """The three opaque byte buffers of one forward call (geometry / binning / image).
+
+    Plays the role of the reference's resizeFunctional lambdas
+    (rasterize_points.cu:28-34): the C library asks for ``bytes`` of device
+    memory and torch owns the allocation.
+    """
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = {}
+        self.callback = _capi.ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, which, nbytes):
+        try:
+            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+        except Exception:  # out of memory: report NULL to the C side, which returns FDGS_ERR_ALLOC
+            return None
+        self.buf[int(which)] = t
+        return t.data_ptr()
+
+    def get(self, which):
+        t = self.buf.get(which)
+        return t if t is not None else torch.empty(0, dtype=torch.uint8, device=self.device)
+
+
+class _NativeRasterizer:
+    """Stand-in for the reference's pybind module ``_C`` (ext.cpp:15-19)."""
+
+    @staticmethod
+    def _scene(bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r, scale_modifier,
+               cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, degree_t,
+               campos, timestamp, time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug):
+        if means3D.ndim != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:69-71
+        f = _capi._dev_f32
+        keep = {
+            "bg": f(bg, "bg"), "means3D": f(means3D, "means3D"), "shs": f(sh, "sh"),
+            "colors_precomp": f(colors, "colors_precomp"), "flows": f(flows, "flow_2d"),
+            "opacities": f(opacity, "opacities"), "ts": f(ts, "ts"), "scales": f(scales, "scales"),
+            "scales_t": f(scales_t, "scales_t"), "rotations": f(rotations, "rotations"),
+            "rotations_r": f(rotations_r, "rotations_r"), "cov3D_precomp": f(cov3D_precomp, "cov3D_precomp"),
+            "viewmatrix": f(viewmatrix, "viewmatrix"), "projmatrix": f(projmatrix, "projmatrix"),
+            "campos": f(campos, "campos"),
+        }
+        s = _capi.FdgsScene()
+        s.P = int(means3D.shape[0])
+        s.D, s.D_t = int(degree), int(degree_t)
+        s.M = int(sh.shape[1]) if _is_given(sh) else 0  # rasterize_points.cu:99-103
+        s.W, s.H = int(W), int(H)
+        for k, t in keep.items():
+            setattr(s, k, _capi._ptr(t))
+        s.scale_modifier, s.prefilter_var = float(scale_modifier), float(prefilter_var)
+        s.tan_fovx, s.tan_fovy = float(tan_fovx), float(tan_fovy)
+        s.timestamp, s.time_duration = float(timestamp), float(time_duration)
+        s.rot_4d, s.gaussian_dim, s.force_sh_3d = int(bool(rot_4d)), int(gaussian_dim), int(bool(force_sh_3d))
+        s.prefiltered, s.debug = int(bool(prefiltered)), int(bool(debug))
+        return s, keep
+
+    def rasterize_gaussians(self, bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
+                            scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                            image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
+                            gaussian_dim, force_sh_3d, prefiltered, debug):
+        """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49)."""
+        if not means3D.is_cuda:
+            raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
+        dev = means3D.device
+        scene, keep = self._scene(bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
+                                  scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx,
+                                  tan_fovy, image_height, image_width, sh, degree, degree_t, campos, timestamp,
+                                  time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug)
+        P, H, W = scene.P, scene.H, scene.W
+        fo = dict(dtype=torch.float32, device=dev)
+        # every output is fully written by the kernels: torch.empty, not torch.full (rasterize_points.cu:80-85)
+        out_color = torch.empty((3, H, W), **fo)
+        out_flow = torch.empty((2, H, W), **fo)
+        out_depth = torch.empty((1, H, W), **fo)
+        out_T = torch.empty((1, H, W), **fo)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        out_means3D = torch.empty((P, 3), **fo)
+        covs_com = torch.empty((P, 6), **fo)  # owning, not a from_blob alias of the scratch (rasterize_points.cu:144-147)
+        out = _capi.FdgsForwardOut(out_color.data_ptr(), out_flow.data_ptr(), out_depth.data_ptr(), out_T.data_ptr(),
+                                   _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com))
+        scratch = _Scratch(dev)
+        R = C.c_int32(0)
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), scratch.callback, None,
+                                                  _capi.current_stream_handle(dev), C.byref(R))
+        _capi._check(rc, "fdgs_rasterize_forward")
+        del keep
+        return (int(R.value), out_color, out_flow, out_depth, out_T, radii,
+                scratch.get(_capi.FDGS_BUF_GEOMETRY), scratch.get(_capi.FDGS_BUF_BINNING),
+                scratch.get(_capi.FDGS_BUF_IMAGE), covs_com, out_means3D)
+
+    def rasterize_gaussians_backward(self, bg, means3D, out_means3D, radii, colors, flows_2d, opacities, ts, scales,
+                                     scales_t, rotations, rotations_r, scale_modifier, cov3D_precomp, prefilter_var,
+                                     viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                     dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
+                                     time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
+                                     imageBuffer, debug):
+        """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89)."""
+        dev = means3D.device
+        H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])  # rasterize_points.cu:192-193
+        scene, keep = self._scene(bg, means3D, colors, flows_2d, opacities, ts, scales, scales_t, rotations,
+                                  rotations_r, scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix,
+                                  tan_fovx, tan_fovy, H, W, sh, degree, degree_t, campos, timestamp, time_duration,
+                                  rot_4d, gaussian_dim, force_sh_3d, False, debug)
+        P, M = scene.P, scene.M
+        fo = dict(dtype=torch.float32, device=dev)
+        # fully written by the kernels (the reference zero-fills all 13 with torch::zeros, rasterize_points.cu:201-213)
+        g = {
+            "dL_dmeans2D": torch.empty((P, 3), **fo), "dL_dcolors": torch.empty((P, 3), **fo),
+            "dL_dopacity": torch.empty((P, 1), **fo), "dL_dmeans3D": torch.empty((P, 3), **fo),
+            "dL_dcov3D": torch.empty((P, 6), **fo), "dL_dsh": torch.empty((P, M, 3), **fo),
+            "dL_dflows": torch.empty((P, 2), **fo), "dL_dts": torch.empty((P, 1), **fo),
+            "dL_dscales": torch.empty((P, 3), **fo), "dL_dscales_t": torch.empty((P, 1), **fo),
+            "dL_drotations": torch.empty((P, 4), **fo), "dL_drotations_r": torch.empty((P, 4), **fo),
+            "dL_dconic": torch.empty((P, 2, 2), **fo),
+        }
+        gin = [_capi._dev_f32(t, n) for t, n in ((dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"),
+                                                 (dL_dout_mask, "dL_dout_mask"), (dL_dout_flow, "dL_dout_flow"))]
+        radii_c, om_c = radii.contiguous(), out_means3D.contiguous()
+        bin_ = _capi.FdgsBackwardIn(gin[0].data_ptr(), gin[1].data_ptr(), gin[2].data_ptr(), gin[3].data_ptr(),
+                                    _capi._ptr(radii_c), _capi._ptr(om_c), _capi._ptr(geomBuffer),
+                                    _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R))
+        bout = _capi.FdgsBackwardOut(*[_capi._ptr(g[k]) for k in (
+            "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
+            "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r", "dL_dconic")])
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
+                                                   _capi.current_stream_handle(dev))
+        _capi._check(rc, "fdgs_rasterize_backward")
+        del keep
+        return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
+                g["dL_dflows"], g["dL_dts"], g["dL_dscales"], g["dL_dscales_t"], g["dL_drotations"],
+                g["dL_drotations_r"])
+
+    def mark_visible(self, means3D, viewmatrix, projmatrix):
+        """rasterize_points.cu:272-291: bool[P], True where view-space z > 0.2."""
+        if not means3D.is_cuda:
+            raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        present = torch.zeros((P,), dtype=torch.bool, device=dev)
+        m = _capi._dev_f32(means3D, "means3D")
+        v = _capi._dev_f32(viewmatrix, "viewmatrix")
+        p = _capi._dev_f32(projmatrix, "projmatrix")
+        if P:
+            with torch.cuda.device(dev):
+                rc = _capi.lib.fdgs_mark_visible(P, m.data_ptr(), v.data_ptr(), _capi._ptr(p), present.data_ptr(),
+                                                 _capi.current_stream_handle(dev))
+            _capi._check(rc, "fdgs_mark_visible")
+        return present
+
+
+_C = _NativeRasterizer()
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(x.cpu().clone() if isinstance(x, torch.Tensor) else x for x in input_tuple)
+
+
+def _call_native(fn, args, debug, dump_name, where):
+    """debug mode keeps the reference behaviour: snapshot the arguments and dump them if the native call throws
+    (gaussian_renderer/diff_gaussian_rasterization.py:122-129, 193-202)."""
+    if not debug:
+        return fn(*args)
+    snapshot = cpu_deep_copy_tuple(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(snapshot, dump_name)
+        print("\nAn error occured in %s. Please forward %s for debugging." % (where, dump_name))
+        raise
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    sh_degree_t: int
+    campos: torch.Tensor
+    timestamp: float
+    time_duration: float
+    rot_4d: bool
+    gaussian_dim: int
+    force_sh_3d: bool
+    prefiltered: bool
+    debug: bool
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, flow_2d, opacities, ts, scales, scales_t, rotations,
+                rotations_r, cov3Ds_precomp, prefilter_var, raster_settings):
+        rs = raster_settings
+        native_args = (
+            rs.bg, means3D, colors_precomp, flow_2d, opacities, ts, scales, scales_t, rotations, rotations_r,
+            rs.scale_modifier, cov3Ds_precomp, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+            rs.image_height, rs.image_width, sh, rs.sh_degree, rs.sh_degree_t, rs.campos, rs.timestamp,
+            rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, rs.prefiltered, rs.debug,
+        )
+        (num_rendered, color, flow, depth, T, radii, geomBuffer, binningBuffer, imgBuffer, covs_com,
+         out_means3D) = _call_native(_C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.prefilter_var = prefilter_var
+        ctx.save_for_backward(colors_precomp, means3D, out_means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              flow_2d, opacities, ts, scales_t, rotations_r, geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, 1 - T, flow, covs_com
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, grad_flow, grad_covs_com):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, out_means3D, scales, rotations, cov3Ds_precomp, radii, sh, flow_2d, opacities, ts,
+         scales_t, rotations_r, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+        native_args = (
+            rs.bg, means3D, out_means3D, radii, colors_precomp, flow_2d, opacities, ts, scales, scales_t, rotations,
+            rotations_r, rs.scale_modifier, cov3Ds_precomp, ctx.prefilter_var, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, grad_flow, sh, rs.sh_degree,
+            rs.sh_degree_t, rs.campos, rs.timestamp, rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d,
+            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug,
+        )
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_flows,
+         grad_ts, grad_scales, grad_scales_t, grad_rotations, grad_rotations_r) = _call_native(
+            _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
+
+        def shaped(given, g):
+            """gradient reshaped like its input, or None when that optional input was absent"""
+            return g.reshape(given.shape) if _is_given(given) else None
+
+        # order = forward's inputs (gaussian_renderer/diff_gaussian_rasterization.py:208-225)
+        return (
+            grad_means3D, grad_means2D, shaped(sh, grad_sh), shaped(colors_precomp, grad_colors_precomp),
+            shaped(flow_2d, grad_flows), shaped(opacities, grad_opacities), shaped(ts, grad_ts),
+            shaped(scales, grad_scales), shaped(scales_t, grad_scales_t), shaped(rotations, grad_rotations),
+            shaped(rotations_r, grad_rotations_r), shaped(cov3Ds_precomp, grad_cov3Ds_precomp), None, None,
+        )
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, flow_2d, opacities, ts, scales, scales_t, rotations,
+                        rotations_r, cov3Ds_precomp, prefilter_var, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, flow_2d, opacities, ts, scales, scales_t,
+                                     rotations, rotations_r, cov3Ds_precomp, prefilter_var, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points in front of the near plane (frustum culling for the camera)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, flow_2d=None, ts=None, scales=None,
+                scales_t=None, rotations=None, rotations_r=None, cov3D_precomp=None, prefilter_var=-1.0):
+        rs = self.raster_settings
+
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (have_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if rs.rot_4d and cov3D_precomp is None and (rotations_r is None or scales_t is None or ts is None):
+            raise Exception('Please provide exactly rotations_r and scales_t and ts if rot_4d and cov3D_precomp is None!')
+
+        # absent tensors travel as empty CPU tensors == NULL pointers
+        # (gaussian_renderer/diff_gaussian_rasterization.py:282-300)
+        def absent(t):
+            return torch.Tensor([]) if t is None else t
+
+        return rasterize_gaussians(means3D, means2D, absent(shs), absent(colors_precomp), absent(flow_2d), opacities,
+                                   absent(ts), absent(scales), absent(scales_t), absent(rotations),
+                                   absent(rotations_r), absent(cov3D_precomp), prefilter_var, rs)

@@ -1,0 +1,194 @@
+/* fdgs.h -- C ABI of libfdgs.so, the MI355X-native differentiable 4D Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * `diff_gaussian_rasterization._C` (diff-gaussian-rasterization/ext.cpp:15-19):
+ *
+ *   fdgs_rasterize_forward   replaces  rasterize_gaussians           (rasterize_points.h:18-49,
+ *                                                                     RasterizeGaussiansCUDA rasterize_points.cu:36-149)
+ *   fdgs_rasterize_backward  replaces  rasterize_gaussians_backward  (rasterize_points.h:51-89,
+ *                                                                     RasterizeGaussiansBackwardCUDA rasterize_points.cu:151-270)
+ *   fdgs_mark_visible        replaces  mark_visible                  (rasterize_points.h:91-94, rasterize_points.cu:272-291)
+ *
+ * Plain C: raw DEVICE pointers, sizes, scalars, an explicit HIP stream and int
+ * error codes.  No torch / pybind types.  The host binding (ctypes in
+ * 4d-gaussian-splatting_amd/_capi.py; any other FFI would look the same, see
+ * INTEGRATION.md) owns every tensor, exactly like the reference where torch owns all
+ * memory and the rasterizer only borrows pointers.
+ *
+ * Conventions carried over from the reference:
+ *  - an absent optional tensor is a NULL pointer (the reference passes empty
+ *    tensors, i.e. data_ptr()==nullptr, gaussian_renderer/diff_gaussian_rasterization.py:282-300);
+ *    precedence: cov3D_precomp > rot_4d (4D conditional) > 3D (+1-D temporal marginal);
+ *  - viewmatrix / projmatrix are the transposed ("row-vector") matrices of
+ *    scene/cameras.py:65-70, read flat as column-major (auxiliary.h:59-78);
+ *  - quaternions are (w,x,y,z) and already normalised; scales are post-exp;
+ *    opacities post-sigmoid; shs is [P, M, 3];
+ *  - the three scratch buffers (geometry / binning / image) are opaque byte
+ *    buffers obtained through a resize callback (the reference's
+ *    resizeFunctional, rasterize_points.cu:28-34) and must be handed back
+ *    unchanged to fdgs_rasterize_backward;
+ *  - gradients are bug-compatible with the reference backward (SURVEY.md
+ *    Appendix A, Q1-Q13).
+ *
+ * All functions are re-entrant and keep no global state besides a thread-local
+ * last-error string.  All work is enqueued on `stream`; fdgs_rasterize_forward
+ * synchronises that stream once (to read back num_rendered, as the reference
+ * does at rasterizer_impl.cu:302).
+ */
+#ifndef FDGS_H
+#define FDGS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDGS_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define FDGS_OK 0
+#define FDGS_ERR_INVALID_ARG 1   /* bad sizes / missing required pointers          */
+#define FDGS_ERR_HIP 2           /* a HIP runtime call or kernel launch failed     */
+#define FDGS_ERR_ALLOC 3         /* the scratch allocator callback returned NULL   */
+#define FDGS_ERR_UNSUPPORTED 4   /* e.g. no gfx950 device                          */
+
+/* which scratch buffer the allocator is asked for */
+#define FDGS_BUF_GEOMETRY 0
+#define FDGS_BUF_BINNING 1
+#define FDGS_BUF_IMAGE 2
+
+/* Resize callback: must return a DEVICE pointer to at least `bytes` bytes,
+ * 256-byte aligned, valid until the matching backward has finished.
+ * Mirrors std::function<char*(size_t)> in CudaRasterizer::Rasterizer::forward
+ * (rasterizer.h:28-31). */
+typedef void* (*fdgs_alloc_fn)(void* user, int which, size_t bytes);
+
+/* Everything that describes one view; shared by forward and backward
+ * (GaussianRasterizationSettings, gaussian_renderer/diff_gaussian_rasterization.py:227-245,
+ * plus the per-call tensors). */
+typedef struct fdgs_scene
+{
+	int32_t P;            /* number of Gaussians                                   */
+	int32_t D, D_t, M;    /* active SH degree, active time degree, SH coeffs/pt    */
+	int32_t W, H;         /* image_width, image_height                             */
+	const float* bg;              /* [3]                                           */
+	const float* means3D;         /* [P,3]                                         */
+	const float* shs;             /* [P,M,3] or NULL                               */
+	const float* colors_precomp;  /* [P,3]  or NULL (exactly one of shs/colors)    */
+	const float* flows;           /* [P,2]  or NULL (NULL == all zero)             */
+	const float* opacities;       /* [P]                                           */
+	const float* ts;              /* [P]    or NULL                                */
+	const float* scales;          /* [P,3]  or NULL                                */
+	const float* scales_t;        /* [P]    or NULL                                */
+	const float* rotations;       /* [P,4]  or NULL                                */
+	const float* rotations_r;     /* [P,4]  or NULL                                */
+	const float* cov3D_precomp;   /* [P,6]  or NULL                                */
+	const float* viewmatrix;      /* [16]                                          */
+	const float* projmatrix;      /* [16]                                          */
+	const float* campos;          /* [3]                                           */
+	float scale_modifier;
+	float prefilter_var;
+	float tan_fovx, tan_fovy;
+	float timestamp, time_duration;
+	int32_t rot_4d, gaussian_dim, force_sh_3d;
+	int32_t prefiltered;
+	int32_t debug;        /* != 0: synchronise + check after every stage (CHECK_CUDA, auxiliary.h:165-172) */
+} fdgs_scene;
+
+/* Forward outputs; every array is fully written by the call (no pre-zeroing needed). */
+typedef struct fdgs_forward_out
+{
+	float* out_color;     /* [3,H,W]                                               */
+	float* out_flow;      /* [2,H,W]                                               */
+	float* out_depth;     /* [1,H,W]                                               */
+	float* out_T;         /* [1,H,W]  final transmittance (Python returns 1 - T)   */
+	int32_t* radii;       /* [P]                                                   */
+	float* out_means3D;   /* [P,3]    means3D, shifted by the conditional mean where rot_4d */
+	float* covs_com;      /* [P,6] or NULL: owning copy of the computed 3D covariances
+	                         (zero for culled Gaussians; the reference returns uninitialised memory there) */
+} fdgs_forward_out;
+
+/* Upstream gradients (d loss / d forward outputs). */
+typedef struct fdgs_backward_in
+{
+	const float* dL_dout_color;  /* [3,H,W]                                        */
+	const float* dL_dout_depth;  /* [1,H,W]                                        */
+	const float* dL_dout_alpha;  /* [1,H,W]  gradient w.r.t. alpha = 1 - T         */
+	const float* dL_dout_flow;   /* [2,H,W]                                        */
+	const int32_t* radii;        /* [P]  as returned by forward                    */
+	const float* out_means3D;    /* [P,3] as returned by forward                   */
+	const void* geom_buffer;     /* the three scratch buffers of the forward call  */
+	const void* binning_buffer;
+	const void* image_buffer;
+	int32_t num_rendered;        /* R returned by forward                          */
+} fdgs_backward_in;
+
+/* Gradients; every non-NULL array is fully written by the call (no pre-zeroing
+ * needed).  dL_dsh may be NULL when M == 0; the 4D-only ones may be NULL when
+ * the corresponding input is absent. */
+typedef struct fdgs_backward_out
+{
+	float* dL_dmeans2D;     /* [P,3]  (x,y in NDC-scaled units, z = depth carrier, Q10) */
+	float* dL_dcolors;      /* [P,3]                                               */
+	float* dL_dopacity;     /* [P]                                                 */
+	float* dL_dmeans3D;     /* [P,3]                                               */
+	float* dL_dcov3D;       /* [P,6]                                               */
+	float* dL_dsh;          /* [P,M,3]                                             */
+	float* dL_dflows;       /* [P,2]                                               */
+	float* dL_dts;          /* [P]                                                 */
+	float* dL_dscales;      /* [P,3]                                               */
+	float* dL_dscales_t;    /* [P]                                                 */
+	float* dL_drotations;   /* [P,4]                                               */
+	float* dL_drotations_r; /* [P,4]                                               */
+	float* dL_dconic;       /* [P,4]  scratch for the 2D conic gradient (Q12 layout) */
+} fdgs_backward_out;
+
+/* Forward pass: preprocess -> depth sort -> scan -> instance emission -> tile
+ * sort -> tile ranges -> per-tile blend.  *num_rendered receives R.
+ * `stream` is a hipStream_t passed as void* so that this header needs no HIP include. */
+int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
+                           fdgs_alloc_fn alloc, void* alloc_user, void* stream,
+                           int32_t* num_rendered);
+
+/* Backward pass: blend backward -> fused cov2D / projection / SH / covariance backward. */
+int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,
+                            const fdgs_backward_out* out, void* stream);
+
+/* present[i] = view-space z of means3D[i] > 0.2 (checkFrustum, rasterizer_impl.cu:54-67). */
+int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present, void* stream);
+
+/* Sizes of the opaque scratch buffers (what the allocator will be asked for). */
+size_t fdgs_geometry_bytes(int32_t P);
+size_t fdgs_image_bytes(int32_t W, int32_t H);
+size_t fdgs_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
+
+/* Introspection for parity tests: device pointers into the opaque buffers of a
+ * finished forward call.  Arrays are indexed as documented in DESIGN.md. */
+typedef struct fdgs_debug_view
+{
+	const float* depths;           /* [P]   view-space z (0 where culled)          */
+	const float* records;          /* [P,12] packed blend record: x,y,conic(3),opacity,r,g,b,depth,flow(2) */
+	const float* cov3D;            /* [P,6]                                        */
+	const uint32_t* tiles_touched; /* [P]                                          */
+	const uint8_t* clamped;        /* [P]   bit c set: colour channel c clamped    */
+	const uint32_t* depth_order;   /* [P]   Gaussian ids sorted by depth bits (stable) */
+	const uint32_t* point_list;    /* [R]   Gaussian ids sorted by (tile, depth, id) */
+	const uint32_t* tile_keys;     /* [R]   tile id of each sorted instance        */
+	const uint32_t* ranges;        /* [T,2]                                        */
+	const uint32_t* n_contrib;     /* [H*W]                                        */
+	const float* final_T;          /* [H*W]                                        */
+} fdgs_debug_view;
+int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
+                     const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                     fdgs_debug_view* view);
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* fdgs_last_error(void);
+int fdgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDGS_H */

@@ -1,0 +1,174 @@
+"""Shared helpers for the parity tests: run the HIP product through its C ABI, run an oracle, compare."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from fdgs import synth  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+PIX_TOL = 1e-4     # north_star: pixels within 1e-4 abs
+GRAD_TOL = 1e-4    # gradients: 1e-4 abs for O(1) tensors, else 1e-4 of the tensor's max magnitude
+GRAD_SCALE = 1e-2  # upstream-gradient scale used by the tests (keeps most gradient tensors O(1..10))
+
+
+def scene_to_device(scene, device):
+    out = {}
+    for k, v in scene.items():
+        out[k] = v.to(device) if isinstance(v, torch.Tensor) else v
+    return out
+
+
+def native_args_fwd(sc):
+    """The 30 positional arguments of _C.rasterize_gaussians from a scene dict (device tensors)."""
+    e = torch.Tensor([])
+    g = lambda k: sc[k] if sc.get(k) is not None else e  # noqa: E731
+    return (sc["bg"], sc["means3D"], g("colors_precomp"), g("flow_2d"), sc["opacities"], g("ts"), g("scales"),
+            g("scales_t"), g("rotations"), g("rotations_r"), sc.get("scale_modifier", 1.0), g("cov3D_precomp"),
+            sc.get("prefilter_var", -1.0), sc["world_view_transform"], sc["full_proj_transform"], sc["tanfovx"],
+            sc["tanfovy"], sc["H"], sc["W"], g("shs"), sc["sh_degree"], sc["sh_degree_t"], sc["camera_center"],
+            sc["timestamp"], sc["time_duration"], sc["rot_4d"], sc["gaussian_dim"], sc["force_sh_3d"], False,
+            sc.get("debug", False))
+
+
+def _view(buf, ptr, count, dtype):
+    """Slice of an opaque scratch tensor starting at device pointer ``ptr``."""
+    if ptr is None or count == 0:
+        return torch.empty(0, dtype=dtype)
+    off = ptr - buf.data_ptr()
+    nbytes = count * torch.empty(0, dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype)
+
+
+def run_hip(scene, device, grads=None):
+    """Forward (+ optional backward) of the HIP product through the C ABI; returns numpy dicts."""
+    from fdgs import _capi
+    from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
+    sc = scene_to_device(scene, device)
+    res = _C.rasterize_gaussians(*native_args_fwd(sc))
+    (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = res
+    P, W, H = int(sc["means3D"].shape[0]), int(sc["W"]), int(sc["H"])
+    v = _capi.FdgsDebugView()
+    rc = _capi.lib.fdgs_debug_views(P, W, H, R, _capi._ptr(geom), _capi._ptr(binb), _capi._ptr(img), C.byref(v))
+    assert rc == 0, _capi.last_error()
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    torch.cuda.synchronize()
+    rec = _view(geom, v.records, P * 12, torch.float32).reshape(P, 12).cpu().numpy()
+    out = {
+        "R": R,
+        "out_color": color.cpu().numpy(), "out_flow": flow.cpu().numpy(), "out_depth": depth.cpu().numpy()[0],
+        "out_T": T.cpu().numpy()[0], "radii": radii.cpu().numpy(), "out_means3D": out_means3D.cpu().numpy(),
+        "covs_com": covs_com.cpu().numpy(),
+        "depths": _view(geom, v.depths, P, torch.float32).cpu().numpy(),
+        "cov3D": _view(geom, v.cov3D, P * 6, torch.float32).reshape(P, 6).cpu().numpy(),
+        "tiles_touched": _view(geom, v.tiles_touched, P, torch.int32).cpu().numpy().astype(np.uint32),
+        "clamped_bits": _view(geom, v.clamped, P, torch.uint8).cpu().numpy(),
+        "depth_order": _view(geom, v.depth_order, P, torch.int32).cpu().numpy().astype(np.uint32),
+        "point_list": _view(binb, v.point_list, R, torch.int32).cpu().numpy().astype(np.uint32),
+        "tile_keys": _view(binb, v.tile_keys, R, torch.int32).cpu().numpy().astype(np.uint32),
+        "ranges": _view(img, v.ranges, ntiles * 2, torch.int32).reshape(ntiles, 2).cpu().numpy().astype(np.uint32),
+        "n_contrib": _view(img, v.n_contrib, W * H, torch.int32).reshape(H, W).cpu().numpy().astype(np.uint32),
+        "final_T": _view(img, v.final_T, W * H, torch.float32).reshape(H, W).cpu().numpy(),
+        "means2D": rec[:, 0:2].copy(),
+        "conic_opacity": np.concatenate([rec[:, 2:5], rec[:, 5:6]], axis=1),
+        "rgb": rec[:, 6:9].copy(), "rec_depth": rec[:, 9].copy(), "rec_flow": rec[:, 10:12].copy(),
+    }
+    out["clamped"] = np.stack([(out["clamped_bits"] >> i) & 1 for i in range(3)], axis=1).astype(np.uint8)
+    gout = None
+    if grads is not None:
+        e = torch.Tensor([])
+        g = lambda k: sc[k] if sc.get(k) is not None else e  # noqa: E731
+        gd = {k: t.to(device) for k, t in grads.items()}
+        bargs = (sc["bg"], sc["means3D"], out_means3D, radii, g("colors_precomp"), g("flow_2d"), sc["opacities"],
+                 g("ts"), g("scales"), g("scales_t"), g("rotations"), g("rotations_r"), sc.get("scale_modifier", 1.0),
+                 g("cov3D_precomp"), sc.get("prefilter_var", -1.0), sc["world_view_transform"],
+                 sc["full_proj_transform"], sc["tanfovx"], sc["tanfovy"], gd["grad_color"], gd["grad_depth"],
+                 gd["grad_alpha"], gd["grad_flow"], g("shs"), sc["sh_degree"], sc["sh_degree_t"], sc["camera_center"],
+                 sc["timestamp"], sc["time_duration"], sc["rot_4d"], sc["gaussian_dim"], sc["force_sh_3d"], geom, R,
+                 binb, img, sc.get("debug", False))
+        names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
+                 "dL_dscale", "dL_dscale_t", "dL_drot", "dL_drot_r")
+        res = _C.rasterize_gaussians_backward(*bargs)
+        torch.cuda.synchronize()
+        gout = {n: t.cpu().numpy() for n, t in zip(names, res)}
+        for n in ("dL_dopacity", "dL_dts", "dL_dscale_t"):
+            gout[n] = gout[n].reshape(-1)
+    return out, gout
+
+
+def run_oracle(scene, grads=None, kind="port"):
+    o = pyoracle.Oracle(scene, kind=kind)
+    out = dict(o.forward())
+    out["R"] = o.R
+    gout = None
+    if grads is not None:
+        # the kernels receive d loss / d alpha unchanged as dL_dmask (reference diff_gaussian_rasterization.py:176)
+        gout = dict(o.backward(grads["grad_color"], grads["grad_depth"], grads["grad_alpha"], grads["grad_flow"]))
+    o.close()
+    return out, gout
+
+
+def check_forward(hip, ref, label="", precomp_cov=False, precomp_colors=False):
+    """Bit-exact integer / key indexing, 1e-4 pixels (away from flagged threshold cliffs). Returns a report dict."""
+    rep = {}
+    bg = ref["border_g"].astype(bool)
+    assert bg.sum() == 0, "%s: scene has %d Gaussians on the temporal-cull cliff; pick another seed" % (label, bg.sum())
+    vis = ref["radii"] > 0
+    np.testing.assert_array_equal(hip["radii"], ref["radii"], err_msg=label + " radii")
+    np.testing.assert_array_equal(hip["tiles_touched"], ref["tiles_touched"], err_msg=label + " tiles_touched")
+    np.testing.assert_array_equal(hip["depths"][vis].view(np.uint32), ref["depths"][vis].view(np.uint32),
+                                  err_msg=label + " depth bits")
+    np.testing.assert_array_equal(hip["means2D"][vis].view(np.uint32), ref["means2D"][vis].view(np.uint32),
+                                  err_msg=label + " means2D bits")
+    assert hip["R"] == ref["R"], "%s: num_rendered %d vs %d" % (label, hip["R"], ref["R"])
+    np.testing.assert_array_equal(hip["point_list"], ref["point_list"], err_msg=label + " point_list")
+    np.testing.assert_array_equal(hip["tile_keys"], (ref["keys_sorted"] >> np.uint64(32)).astype(np.uint32),
+                                  err_msg=label + " sorted tile ids")
+    np.testing.assert_array_equal(hip["ranges"], ref["ranges"], err_msg=label + " ranges")
+    float_checks = [("out_means3D", 0.0), ("conic_opacity", 1e-6)]
+    if precomp_colors is False:
+        float_checks.append(("rgb", 2e-6))  # with colors_precomp the reference never writes its rgb scratch
+    if precomp_cov is False:
+        float_checks.append(("cov3D", 0.0))  # with cov3D_precomp the reference never writes its cov3D scratch
+    for k, tol in float_checks:
+        a, b = hip[k][vis], ref[k][vis]
+        err = float(np.abs(a - b).max()) if a.size else 0.0
+        rep[k] = err
+        assert err <= tol * max(1.0, float(np.abs(b).max()) if b.size else 1.0), "%s: %s max err %g" % (label, k, err)
+    if precomp_colors is False:
+        np.testing.assert_array_equal(hip["clamped"][vis], ref["clamped"][vis], err_msg=label + " clamped")
+    border = ref["border"].astype(bool)
+    rep["border_frac"] = float(border.mean())
+    assert rep["border_frac"] < 2e-3, "%s: too many cliff pixels %g" % (label, rep["border_frac"])
+    ok = ~border
+    nc_diff = int((hip["n_contrib"][ok] != ref["n_contrib"][ok]).sum())
+    rep["n_contrib_diff_nonborder"] = nc_diff
+    assert nc_diff == 0, "%s: n_contrib differs on %d non-cliff pixels" % (label, nc_diff)
+    for k in ("out_color", "out_flow", "out_depth", "out_T"):
+        a, b = hip[k], ref[k]
+        d = np.abs(a - b)
+        d = d[:, ok] if d.ndim == 3 else d[ok]
+        rep[k] = float(d.max())
+        assert rep[k] <= PIX_TOL, "%s: %s max abs err %g > %g" % (label, k, rep[k], PIX_TOL)
+    np.testing.assert_array_equal(hip["final_T"], hip["out_T"], err_msg=label + " final_T copy")
+    return rep
+
+
+def check_backward(hipg, refg, label="", tol=GRAD_TOL):
+    rep = {}
+    for k, b in refg.items():
+        if k == "dL_dconic":
+            continue
+        a = hipg[k].reshape(b.shape)
+        scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+        err = float(np.abs(a - b).max()) if b.size else 0.0
+        rep[k] = (err, scale)
+        assert np.isfinite(a).all(), "%s: %s has non-finite values" % (label, k)
+        assert err <= tol * scale, "%s: %s max abs err %g > %g (max|ref| %g)" % (label, k, err, tol * scale, scale)
+    return rep
