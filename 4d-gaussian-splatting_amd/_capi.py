@@ -64,7 +64,9 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_last_error", "fdgs_version")
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_profile_enable", "fdgs_profile_read",
+            "fdgs_profile_reset", "fdgs_stage_name", "fdgs_last_error", "fdgs_version")
+NUM_STAGES = 10
 
 
 def _load():
@@ -90,6 +92,13 @@ def _load():
     lib.fdgs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.POINTER(FdgsDebugView)]
     lib.fdgs_debug_views.restype = C.c_int
+    lib.fdgs_profile_enable.argtypes = [C.c_int]
+    lib.fdgs_profile_enable.restype = C.c_int
+    lib.fdgs_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.fdgs_profile_read.restype = C.c_int
+    lib.fdgs_profile_reset.restype = C.c_int
+    lib.fdgs_stage_name.argtypes = [C.c_int]
+    lib.fdgs_stage_name.restype = C.c_char_p
     lib.fdgs_last_error.restype = C.c_char_p
     lib.fdgs_version.restype = C.c_int
     return lib
@@ -131,3 +140,22 @@ def _dev_f32(t, name):
 
 def current_stream_handle(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def profile_enable(on: bool = True):
+    """Bracket every stage with HIP events on the caller's stream (fdgs_profile_enable)."""
+    lib.fdgs_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib.fdgs_profile_reset()
+
+
+def profile_read():
+    """{stage name: (total_ms, samples)} accumulated since the last reset; synchronises pending events."""
+    out = {}
+    for st in range(NUM_STAGES):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        lib.fdgs_profile_read(st, C.byref(ms), C.byref(n))
+        out[lib.fdgs_stage_name(st).decode()] = (ms.value, int(n.value))
+    return out

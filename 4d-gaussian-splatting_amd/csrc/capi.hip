@@ -7,6 +7,8 @@
 // read-back of num_rendered (4 bytes through a pinned staging word), as in the
 // reference (rasterizer_impl.cu:302).
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -31,9 +33,92 @@ static int fail(int code, const char* fmt, ...)
 		if (e__ != hipSuccess) return fail(FDGS_ERR_HIP, "%s: %s", what, hipGetErrorString(e__));   \
 	} while (0)
 
+// ---- optional per-stage HIP-event timing (fdgs_profile_*) ----
+namespace
+{
+	constexpr int PROF_CAP = 256;
+	struct StageProf
+	{
+		hipEvent_t start[PROF_CAP], stop[PROF_CAP];
+		int created = 0, pending = 0;
+		double total_ms = 0.0;
+		long long samples = 0;
+	};
+	// process-wide (autograd runs the backward on its own thread); guarded by g_prof_mu
+	std::atomic<bool> g_prof_on{false};
+	StageProf g_prof[FDGS_NUM_STAGES];
+	std::mutex g_prof_mu;
+
+	void prof_flush(StageProf& p)
+	{
+		for (int i = 0; i < p.pending; i++)
+		{
+			float ms = 0.f;
+			if (hipEventSynchronize(p.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, p.start[i], p.stop[i]) == hipSuccess)
+			{
+				p.total_ms += ms;
+				p.samples++;
+			}
+		}
+		p.pending = 0;
+	}
+	struct StageTimer
+	{
+		StageProf* p = nullptr;
+		hipStream_t stream;
+		int slot = 0;
+		bool locked = false;
+		StageTimer(int stage, hipStream_t s) : stream(s)
+		{
+			if (!g_prof_on.load(std::memory_order_relaxed)) return;
+			g_prof_mu.lock();
+			locked = true;
+			p = &g_prof[stage];
+			if (p->pending == PROF_CAP) prof_flush(*p);
+			slot = p->pending;
+			if (slot >= p->created)
+			{
+				if (hipEventCreate(&p->start[slot]) != hipSuccess || hipEventCreate(&p->stop[slot]) != hipSuccess) { p = nullptr; return; }
+				p->created = slot + 1;
+			}
+			(void)hipEventRecord(p->start[slot], stream);
+		}
+		~StageTimer()
+		{
+			if (p)
+			{
+				(void)hipEventRecord(p->stop[slot], stream);
+				p->pending = slot + 1;
+			}
+			if (locked) g_prof_mu.unlock();
+		}
+	};
+	const char* const STAGE_NAMES[FDGS_NUM_STAGES] = { "preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
+		"tile_sort", "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero" };
+}
+
+extern "C" int fdgs_profile_enable(int on) { g_prof_on.store(on != 0); return FDGS_OK; }
+extern "C" int fdgs_profile_reset(void)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	for (auto& p : g_prof) { prof_flush(p); p.total_ms = 0.0; p.samples = 0; }
+	return FDGS_OK;
+}
+extern "C" int fdgs_profile_read(int stage, double* total_ms, int64_t* samples)
+{
+	if (stage < 0 || stage >= FDGS_NUM_STAGES) return FDGS_ERR_INVALID_ARG;
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	prof_flush(g_prof[stage]);
+	if (total_ms) *total_ms = g_prof[stage].total_ms;
+	if (samples) *samples = g_prof[stage].samples;
+	return FDGS_OK;
+}
+extern "C" const char* fdgs_stage_name(int stage) { return (stage >= 0 && stage < FDGS_NUM_STAGES) ? STAGE_NAMES[stage] : ""; }
+
 // debug mode == the reference's CHECK_CUDA(..., debug): synchronise and check after each stage
-#define STAGE(expr, what)                                                                           \
+#define STAGE(id, expr, what)                                                                       \
 	do {                                                                                            \
+		StageTimer timer__(id, stream);                                                             \
 		HIP_TRY((expr), what);                                                                      \
 		if (debug) HIP_TRY(hipStreamSynchronize(stream), what);                                     \
 	} while (0)
@@ -91,7 +176,6 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	const bool debug = s.debug != 0;
 	const int P = s.P, W = s.W, H = s.H;
 	const int gx = div_up(W, TILE_X), gy = div_up(H, TILE_Y), T = gx * gy;
-	const size_t N = (size_t)W * H;
 	if (!out->out_color || !out->out_flow || !out->out_depth || !out->out_T || (P > 0 && (!out->radii || !out->out_means3D)))
 		return fail(FDGS_ERR_INVALID_ARG, "forward outputs must not be NULL");
 	*num_rendered = 0;
@@ -109,16 +193,16 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	uint32_t* point_list = nullptr;
 	if (P > 0)
 	{
-		STAGE(launch_preprocess_fwd(s, *out, geom, stream), "preprocess_fwd");
+		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, stream), "preprocess_fwd");
 
 		uint32_t* dk[2] = { (uint32_t*)(geom + GL.sort_key[0]), (uint32_t*)(geom + GL.sort_key[1]) };
 		uint32_t* dv[2] = { (uint32_t*)(geom + GL.sort_val[0]), (uint32_t*)(geom + GL.sort_val[1]) };
 		int dres = 0;
-		STAGE(radix_sort_pairs(dk, dv, P, 0, 32, (uint32_t*)(geom + GL.hist), stream, &dres), "depth sort");
+		STAGE(FDGS_STAGE_DEPTH_SORT, radix_sort_pairs(dk, dv, P, 0, 32, (uint32_t*)(geom + GL.hist), stream, &dres), "depth sort");
 		const uint32_t* order = dv[dres];
 
 		uint32_t* block_sums = (uint32_t*)(geom + GL.scan_block);
-		STAGE(launch_offsets_scan((const uint32_t*)(geom + GL.tiles_touched), order, P,
+		STAGE(FDGS_STAGE_OFFSET_SCAN, launch_offsets_scan((const uint32_t*)(geom + GL.tiles_touched), order, P,
 		                          (uint32_t*)(geom + GL.offsets), block_sums, stream), "offset scan");
 
 		// num_rendered read-back (the one host sync of the forward pass)
@@ -140,24 +224,18 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		uint32_t* tk[2] = { (uint32_t*)(bin + BL.key[0]), (uint32_t*)(bin + BL.key[1]) };
 		uint32_t* tv[2] = { (uint32_t*)(bin + BL.val[0]), (uint32_t*)(bin + BL.val[1]) };
 		const int dres = final_buf(4);
-		STAGE(launch_emit_instances((const uint32_t*)(geom + GL.sort_val[dres]), (const uint32_t*)(geom + GL.offsets),
+		STAGE(FDGS_STAGE_EMIT, launch_emit_instances((const uint32_t*)(geom + GL.sort_val[dres]), (const uint32_t*)(geom + GL.offsets),
 		                            (const uint16_t*)(geom + GL.rect), P, R, gx, tk[0], tv[0], stream), "emit instances");
 		int tres = 0;
-		STAGE(radix_sort_pairs(tk, tv, R, 0, tile_sort_passes(T) * RADIX_BITS, (uint32_t*)(bin + BL.hist), stream, &tres), "tile sort");
-		STAGE(launch_tile_ranges(tk[tres], R, T, ranges, stream), "tile ranges");
+		STAGE(FDGS_STAGE_TILE_SORT, radix_sort_pairs(tk, tv, R, 0, tile_sort_passes(T) * RADIX_BITS, (uint32_t*)(bin + BL.hist), stream, &tres), "tile sort");
+		STAGE(FDGS_STAGE_TILE_RANGES, launch_tile_ranges(tk[tres], R, T, ranges, stream), "tile ranges");
 		point_list = tv[tres];
 	}
 	else
-		STAGE(hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
+		STAGE(FDGS_STAGE_TILE_RANGES, hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
 
-	fdgs_scene s2 = s;
-	if (P == 0)
-	{
-		// nothing to blend: the kernel still writes background colour / T = 1 everywhere
-		static const uint32_t dummy = 0; (void)dummy;
-	}
-	STAGE(launch_blend_fwd(s2, *out, (const float*)(geom + GL.records), point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
-	(void)N;
+	// with nothing to blend the kernel still writes background colour / T = 1 everywhere
+	STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, (const float*)(geom + GL.records), point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
 	return FDGS_OK;
 }
 
@@ -197,16 +275,16 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	const uint32_t* point_list = (const uint32_t*)(bin + BL.val[tres]);
 
 	// the five atomically-accumulated per-Gaussian gradients start from zero
-	STAGE(hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, stream), "memset");
-	STAGE(hipMemsetAsync(out->dL_dconic, 0, (size_t)P * 16, stream), "memset");
-	STAGE(hipMemsetAsync(out->dL_dopacity, 0, (size_t)P * 4, stream), "memset");
-	STAGE(hipMemsetAsync(out->dL_dcolors, 0, (size_t)P * 12, stream), "memset");
-	STAGE(hipMemsetAsync(out->dL_dflows, 0, (size_t)P * 8, stream), "memset");
+	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, stream), "memset");
+	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dconic, 0, (size_t)P * 16, stream), "memset");
+	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dopacity, 0, (size_t)P * 4, stream), "memset");
+	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dcolors, 0, (size_t)P * 12, stream), "memset");
+	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dflows, 0, (size_t)P * 8, stream), "memset");
 
 	if (R > 0)
-		STAGE(launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
+		STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
 		                       (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
-	STAGE(launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
+	STAGE(FDGS_STAGE_PREPROCESS_BWD, launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
 	return FDGS_OK;
 }
 

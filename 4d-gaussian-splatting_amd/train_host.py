@@ -1,0 +1,165 @@
+"""Host-side (PyTorch) pieces of one frame-parallel train step around the native rasterizer.
+
+These mirror what the reference trainer does on either side of the hot path
+(train.py:104-166, 247-249) so that ``bench.py`` times the metric BASELINE.md defines
+(render forward -> L1 + D-SSIM -> backward -> optimizer step) and so that the multi-GPU
+exchange of SURVEY.md section 8e has one implementation that the CPU ``gloo`` tests
+and the RCCL bench share:
+
+* ``GaussianParams``  -- the reference's parameter set and activations
+  (scene/gaussian_model.py:179-219: exp scales, sigmoid opacity, normalised
+  quaternions, ``cat(features_dc, features_rest)``), duck-typed for ``render()``.
+  All parameters are views into ONE flat fp32 buffer and all gradients into ONE
+  flat gradient buffer, so the data-parallel exchange is a single collective.
+* ``allreduce_gradients`` -- one ``all_reduce(SUM)`` over the flat gradient bucket
+  (161 floats per Gaussian at M = 48 -> 193 MB at 300 k Gaussians), then the 1/world
+  scale of ``loss / batch_size`` (train.py:162).  Frames / timesteps are independent
+  given the parameters, so there is no collective inside the rasterizer itself.
+* ``l1_loss`` / ``ssim`` / ``photometric_loss`` -- utils/loss_utils.py:17-64 semantics
+  (11x11 Gaussian window, sigma 1.5, C1 = 0.01^2, C2 = 0.03^2; lambda_dssim = 0.2).
+"""
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def _inv_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianParams:
+    """Flat-bucket parameter set with the reference model's getters (post-activation)."""
+
+    NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_t", "_scaling_t",
+             "_rotation_r")
+
+    def __init__(self, scene: Dict[str, object], device):
+        """``scene``: post-activation tensors from fdgs.synth.make_scene; raw parameters are their inverses."""
+        P, M = int(scene["means3D"].shape[0]), int(scene["M"])
+        shapes = {"_xyz": (P, 3), "_features_dc": (P, 1, 3), "_features_rest": (P, M - 1, 3), "_opacity": (P, 1),
+                  "_scaling": (P, 3), "_rotation": (P, 4), "_t": (P, 1), "_scaling_t": (P, 1), "_rotation_r": (P, 4)}
+        init = {"_xyz": scene["means3D"], "_features_dc": scene["shs"][:, :1, :], "_features_rest": scene["shs"][:, 1:, :],
+                "_opacity": _inv_sigmoid(scene["opacities"].clamp(1e-6, 1 - 1e-6)), "_scaling": torch.log(scene["scales"]),
+                "_rotation": scene["rotations"], "_t": scene["ts"], "_scaling_t": torch.log(scene["scales_t"]),
+                "_rotation_r": scene["rotations_r"]}
+        total = sum(int(torch.tensor(s).prod()) for s in shapes.values())
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.params: Dict[str, torch.Tensor] = {}
+        off = 0
+        for name in self.NAMES:
+            n = int(torch.tensor(shapes[name]).prod())
+            view = self.flat[off:off + n].view(shapes[name])
+            view.copy_(init[name].to(device).reshape(shapes[name]))
+            p = view.requires_grad_(True)
+            p.grad = self.flat_grad[off:off + n].view(shapes[name])
+            self.params[name] = p
+            off += n
+        self.P, self.M = P, M
+        self.active_sh_degree = int(scene["sh_degree"])
+        self.active_sh_degree_t = int(scene["sh_degree_t"])
+        self.time_duration = [0.0, float(scene["time_duration"])]
+        self.rot_4d, self.gaussian_dim = bool(scene["rot_4d"]), int(scene["gaussian_dim"])
+        self.force_sh_3d = bool(scene["force_sh_3d"])
+        self.prefilter_var = -1.0
+        self.env_map = None
+        self.get_max_sh_channels = M
+
+    # ---- scene/gaussian_model.py:179-219 ----
+    get_xyz = property(lambda s: s.params["_xyz"])
+    get_t = property(lambda s: s.params["_t"])
+    get_scaling = property(lambda s: torch.exp(s.params["_scaling"]))
+    get_scaling_t = property(lambda s: torch.exp(s.params["_scaling_t"]))
+    get_rotation = property(lambda s: F.normalize(s.params["_rotation"]))
+    get_rotation_r = property(lambda s: F.normalize(s.params["_rotation_r"]))
+    get_opacity = property(lambda s: torch.sigmoid(s.params["_opacity"]))
+    get_features = property(lambda s: torch.cat((s.params["_features_dc"], s.params["_features_rest"]), dim=1))
+
+    def optimizer_groups(self) -> List[dict]:
+        """Learning rates of arguments/__init__.py:84-92 (spatial_lr_scale = 1)."""
+        lr = {"_xyz": 1.6e-4, "_features_dc": 2.5e-3, "_features_rest": 2.5e-3 / 20.0, "_opacity": 5e-2, "_scaling": 5e-3,
+              "_rotation": 1e-3, "_t": 1.6e-4, "_scaling_t": 5e-3, "_rotation_r": 1e-3}
+        return [{"params": [self.params[n]], "lr": lr[n], "name": n} for n in self.NAMES]
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+
+def make_optimizer(model: GaussianParams) -> torch.optim.Optimizer:
+    """torch.optim.Adam(lr=0, eps=1e-15) as scene/gaussian_model.py:353; fused/foreach where the device supports it."""
+    groups = model.optimizer_groups()
+    try:
+        return torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=model.flat.is_cuda)
+    except (RuntimeError, TypeError):
+        return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+
+def allreduce_gradients(model: GaussianParams, world_size: int) -> None:
+    """One collective over the flat gradient bucket; grads become the mean over ranks (loss / batch_size)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(model.flat_grad, op=dist.ReduceOp.SUM)
+        model.flat_grad.mul_(1.0 / world_size)
+
+
+# ------------------------- utils/loss_utils.py:17-64 -------------------------
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+_WINDOWS: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def _window(window_size: int, channel: int, like: torch.Tensor) -> torch.Tensor:
+    key = (window_size, channel, str(like.device))
+    w = _WINDOWS.get(key)
+    if w is None:
+        g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+        g = (g / g.sum()).unsqueeze(1)
+        w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+        w = w2.expand(channel, 1, window_size, window_size).contiguous().to(like.device).type_as(like)
+        _WINDOWS[key] = w
+    return w
+
+
+def ssim(img1, img2, window_size=11):
+    channel = img1.size(-3)
+    w = _window(window_size, channel, img1)
+    pad = window_size // 2
+    x1, x2 = img1.unsqueeze(0) if img1.dim() == 3 else img1, img2.unsqueeze(0) if img2.dim() == 3 else img2
+    mu1 = F.conv2d(x1, w, padding=pad, groups=channel)
+    mu2 = F.conv2d(x2, w, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    sigma1_sq = F.conv2d(x1 * x1, w, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(x2 * x2, w, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(x1 * x2, w, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean()
+
+
+def photometric_loss(image, gt, lambda_dssim=0.2):
+    """(1 - lambda) L1 + lambda (1 - SSIM), train.py:115-117."""
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+class SyntheticCamera:
+    """Duck-typed scene.cameras.Camera built from a fdgs.synth scene dict."""
+
+    def __init__(self, scene, device, timestamp=None):
+        self.FoVx, self.FoVy = scene["FoVx"], scene["FoVy"]
+        self.image_height, self.image_width = scene["H"], scene["W"]
+        self.world_view_transform = scene["world_view_transform"].to(device)
+        self.full_proj_transform = scene["full_proj_transform"].to(device)
+        self.camera_center = scene["camera_center"].to(device)
+        self.timestamp = scene["timestamp"] if timestamp is None else timestamp
+
+
+class PipelineFlags:
+    """arguments/__init__.py:70-79 defaults (in-kernel covariance and SH)."""
+    compute_cov3D_python = False
+    convert_SHs_python = False
+    debug = False
+    env_map_res = 0

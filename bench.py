@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X: train-step images/s (+ forward Mpix/s) on the
+C3 workload (300 k 4D Gaussians, 1352x1014, SH degree 3 + time degree 2 (M = 48), rot_4d + cov_t).
+
+One *step* = one pass of the hot path over one view per rank, structured like the reference's
+training iteration (train.py:104-166, 247-249):
+    activations (exp / sigmoid / normalize / cat, PyTorch) -> render() forward (HIP) ->
+    (1-l) L1 + l (1 - SSIM) (PyTorch) -> backward (HIP + autograd) ->
+    [N > 1: ONE all-reduce of the flat 161*P-float gradient bucket over RCCL] -> Adam step.
+Frames / timesteps shard embarrassingly: rank r renders timestamp (r + 0.5) / N of the sequence with
+replicated parameters (scaling = "weak": one view per GPU per step).  Inputs are synthetic
+(fdgs.synth, seed 0) and resident in HBM before the timed region.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
+        N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                    --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the field definitions).
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+# Algorithmic HBM bytes per launch of each stage (BASELINE.md section 3 / SURVEY.md section 8d):
+# P Gaussians, Pv visible, M SH coefficients, R instances, N pixels, T tiles.
+ALGO_BYTES = {
+    "preprocess_fwd": lambda P, Pv, M, R, N, T: 68 * P + (12 * M + 87) * Pv,
+    "blend_fwd": lambda P, Pv, M, R, N, T: 52 * R + 32 * N,
+    "blend_bwd": lambda P, Pv, M, R, N, T: 96 * R + 36 * N,
+    "preprocess_bwd": lambda P, Pv, M, R, N, T: (68 + 24 * M + 150 + 104) * Pv,  # incl. the fused cov2D backward
+    # our two-level sort: 4 passes over P pairs + 2 passes over R pairs (reads keys for the histogram, then pairs)
+    "depth_sort": lambda P, Pv, M, R, N, T: 4 * (4 + 8 + 8) * P,
+    "tile_sort": lambda P, Pv, M, R, N, T: 2 * (4 + 8 + 8) * R,
+    "emit_instances": lambda P, Pv, M, R, N, T: 8 * R + 16 * P,
+    "offset_scan": lambda P, Pv, M, R, N, T: 20 * P,
+    "tile_ranges": lambda P, Pv, M, R, N, T: 4 * R + 16 * T,
+    "grad_zero": lambda P, Pv, M, R, N, T: 52 * P,
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-loss", action="store_true", help="debug: sum() loss instead of L1 + SSIM")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (see docstring)" % args.gpus)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(scene, samples):
+    """The oracle ("port": scalar C restatement of the reference kernels, OpenMP over Gaussians / tiles)
+    timed on this box's host cores on a bounded sample of the same workload: `samples` full rasterizer
+    forward + backward passes of the same scene (no loss / optimizer: those are PyTorch on both sides)."""
+    from fdgs import synth
+    from oracle import pyoracle
+    o = pyoracle.Oracle(scene, kind="port")
+    g = synth.make_upstream_grads(scene["W"], scene["H"], seed=1, scale=1e-2)
+    o.forward()  # touch pages / build the library
+    t0 = time.perf_counter()
+    for _ in range(samples):
+        o.close()
+        o.forward()
+        o.backward(g["grad_color"], g["grad_depth"], g["grad_alpha"], g["grad_flow"])
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": samples / dt, "unit": "images/s", "cores": pyoracle.threads("port"), "kind": "port",
+            "sample": "%d rasterizer forward+backward passes of the same %s scene (%.1f s of CPU work); "
+                      "oracle/fdgs_oracle.c, gcc -O2 -fopenmp" % (samples, scene["cfg"].name, dt)}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic_r*.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d.get(stage, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    world, rank, local = init_dist(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from fdgs import _capi, synth, train_host
+    from fdgs.gaussian_renderer import render
+
+    cfg = synth.CONFIGS[args.workload]
+    scene = synth.make_scene(cfg, seed=0)
+    model = train_host.GaussianParams(scene, dev)
+    opt = train_host.make_optimizer(model)
+    pipe = train_host.PipelineFlags()
+    ts_frac = (rank + 0.5) / world
+    cam = train_host.SyntheticCamera(scene, dev, timestamp=ts_frac * scene["time_duration"])
+    bg = scene["bg"].to(dev)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    gt = torch.rand(3, scene["H"], scene["W"], generator=gen).to(dev)
+
+    def step():
+        model.zero_grad()
+        pkg = render(cam, model, pipe, bg)
+        loss = pkg["render"].sum() * 1e-6 if args.no_loss else train_host.photometric_loss(pkg["render"], gt)
+        loss.backward()
+        train_host.allreduce_gradients(model, world)
+        opt.step()
+        return pkg
+
+    for _ in range(args.warmup):
+        step()
+    _capi.profile_enable(True)
+    _capi.profile_reset()
+    torch.cuda.synchronize(dev)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pkg = step()
+    torch.cuda.synchronize(dev)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    _capi.profile_enable(False)
+    prof = _capi.profile_read()
+    dt = max_over_ranks(dt, world, dev)
+
+    # forward-only rate (the metric's second half), outside the train-step timing
+    with torch.no_grad():
+        for _ in range(3):
+            render(cam, model, pipe, bg)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            render(cam, model, pipe, bg)
+        torch.cuda.synchronize(dev)
+        dt_fwd = max_over_ranks(time.perf_counter() - t1, world, dev)
+
+    if rank != 0:
+        return
+    P, M, W, H = model.P, model.M, scene["W"], scene["H"]
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    Pv = int((pkg["radii"] > 0).sum().item())
+    R = int(_NUM_RENDERED.get("R", 0))
+    stages = {}
+    for name, (ms, n) in prof.items():
+        if n == 0:
+            continue
+        per_step_ms = ms / args.steps
+        entry = {"ms": round(per_step_ms, 4)}
+        if name in ALGO_BYTES:
+            b = ALGO_BYTES[name](P, Pv, M, R, N, T)
+            entry["algo_bytes"] = int(b)
+            entry["gbps"] = round(b / (per_step_ms * 1e-3) / 1e9, 1) if per_step_ms > 0 else None
+        stages[name] = entry
+    dom = max(stages, key=lambda k: stages[k]["ms"])
+    dom_bytes = ALGO_BYTES[dom](P, Pv, M, R, N, T)
+    achieved = dom_bytes / (stages[dom]["ms"] * 1e-3) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
+                "avg_kernel_ms": stages[dom]["ms"], "algo_bytes_per_launch": int(dom_bytes),
+                "note": "blend kernels are VALU/atomic-bound (SURVEY.md 8d): frac of HBM peak is reported as the contract asks"}
+    out = {
+        "metric": "train-step images/sec + forward Mpix/s, 300k 4D Gaussians @1352x1014",
+        "value": round(world * args.steps / dt, 3),
+        "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
+                               "1 view/GPU/step, L1+SSIM loss, Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
+                                                                        M, cfg.rot_4d),
+                   "num_rendered": R, "visible": Pv, "parallelism": "frame-parallel dp%d" % world},
+        "forward_mpix_s": round(world * args.steps * N / dt_fwd / 1e6, 1),
+        "forward_ms": round(dt_fwd / args.steps * 1e3, 4),
+        "raster_ms": round(sum(v["ms"] for v in stages.values()), 4),
+        "stages": stages,
+        "roofline": roofline,
+    }
+    if world == 1 and args.cpu_samples > 0:
+        out["cpu_baseline"] = cpu_baseline(scene, args.cpu_samples)
+    print(json.dumps(out))
+
+
+_NUM_RENDERED = {}
+
+
+def _install_r_probe():
+    from fdgs.gaussian_renderer import diff_gaussian_rasterization as m
+    orig = m._C.rasterize_gaussians
+
+    def wrapped(*a, **k):
+        res = orig(*a, **k)
+        _NUM_RENDERED["R"] = res[0]
+        return res
+    m._C.rasterize_gaussians = wrapped
+
+
+if __name__ == "__main__":
+    _install_r_probe()
+    main()

@@ -184,6 +184,27 @@ int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                      fdgs_debug_view* view);
 
+/* Optional per-stage timing with HIP events recorded on the caller's stream (so the
+ * numbers are the kernels' own durations on that stream, not host wall time).
+ * Disabled by default; when enabled each stage of forward / backward is bracketed
+ * by an event pair (non-blocking).  fdgs_profile_read synchronises the pending
+ * events and returns the accumulated milliseconds and the number of samples. */
+#define FDGS_STAGE_PREPROCESS_FWD 0
+#define FDGS_STAGE_DEPTH_SORT 1
+#define FDGS_STAGE_OFFSET_SCAN 2
+#define FDGS_STAGE_EMIT 3
+#define FDGS_STAGE_TILE_SORT 4
+#define FDGS_STAGE_TILE_RANGES 5
+#define FDGS_STAGE_BLEND_FWD 6
+#define FDGS_STAGE_BLEND_BWD 7
+#define FDGS_STAGE_PREPROCESS_BWD 8
+#define FDGS_STAGE_GRAD_ZERO 9
+#define FDGS_NUM_STAGES 10
+int fdgs_profile_enable(int on);
+int fdgs_profile_read(int stage, double* total_ms, int64_t* samples);
+int fdgs_profile_reset(void);
+const char* fdgs_stage_name(int stage);
+
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* fdgs_last_error(void);
 int fdgs_version(void);

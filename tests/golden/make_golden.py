@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ with the reference's OWN kernel source compiled for the
+CPU (oracle/_ref/liboracle_ref.so, built by oracle/refbuild/build_ref.py from /root/reference).
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+Each fixture is a compressed .npz holding the seeded inputs (regenerable from fdgs.synth with the stored
+config / seed, kept anyway so the file is self-contained) and every forward intermediate and gradient the
+reference produces: radii, tiles_touched, depths, means2D, conic_opacity, rgb, cov3D, out_means3D, clamped,
+point_offsets, sorted keys, point_list, ranges, n_contrib, final T, images, and the 13 gradient tensors.
+The reference ships no tests or golden vectors for this path: these files are the pin.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from fdgs import synth  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+SC = synth.SceneConfig
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (config, seed, make_scene kwargs)
+FIXTURES = {
+    "rot4d_sh3t2": (SC("g", 400, 80, 64, 3, 2, 0.05, 10.0, True, 4, False), 11, dict(random_flow=True, bg=(0.2, 0.3, 0.4))),
+    "rot4d_sh0": (SC("g", 900, 96, 96, 0, 0, 0.04, 1.0, True, 4, True), 12, dict()),
+    "dim3_sh2": (SC("g", 700, 100, 60, 2, 0, 0.04, 1.0, False, 3, False), 13, dict(random_flow=True)),
+    "dim4_norot_sh1": (SC("g", 700, 90, 70, 1, 0, 0.04, 1.0, False, 4, True), 14, dict(bg=(1.0, 1.0, 1.0))),
+}
+
+INPUT_KEYS = ("means3D", "ts", "scales", "scales_t", "rotations", "rotations_r", "opacities", "shs", "flow_2d", "bg",
+              "world_view_transform", "full_proj_transform", "camera_center")
+SCALAR_KEYS = ("W", "H", "sh_degree", "sh_degree_t", "timestamp", "time_duration", "rot_4d", "gaussian_dim",
+               "force_sh_3d", "scale_modifier", "prefilter_var", "tanfovx", "tanfovy")
+
+
+def scene_for(name):
+    cfg, seed, kw = FIXTURES[name]
+    return synth.make_scene(cfg, seed=seed, **kw)
+
+
+def main():
+    if pyoracle.build_ref() is None:
+        raise SystemExit("needs /root/reference to build oracle/_ref/liboracle_ref.so")
+    for name in FIXTURES:
+        sc = scene_for(name)
+        g = synth.make_upstream_grads(sc["W"], sc["H"], seed=1, scale=1e-2)
+        o = pyoracle.Oracle(sc, kind="reference")
+        out = dict(o.forward())
+        gr = o.backward(g["grad_color"], g["grad_depth"], g["grad_alpha"], g["grad_flow"])
+        data = {}
+        for k in INPUT_KEYS:
+            data["in_" + k] = sc[k].numpy()
+        for k in SCALAR_KEYS:
+            data["sc_" + k] = np.asarray(sc[k])
+        for k, v in g.items():
+            data["up_" + k] = v.numpy()
+        for k, v in out.items():
+            if k in ("border", "border_g"):
+                continue
+            data["fw_" + k] = v
+        data["fw_R"] = np.asarray(o.R)
+        for k, v in gr.items():
+            data["bw_" + k] = v
+        o.close()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **data)
+        print("%-16s R=%6d  %7.1f KiB" % (name, o.R, os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

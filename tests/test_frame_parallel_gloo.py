@@ -1,0 +1,74 @@
+"""CPU, world_size 2 over gloo: the frame-parallel exchange of SURVEY.md section 8e -- ONE all-reduce over the flat
+gradient bucket, replicas stay bit-identical after the optimizer step.  The same GaussianParams /
+allreduce_gradients code runs over RCCL in bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fdgs import train_host
+    cfg = synth.SceneConfig("dp", 257, 64, 48, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=0)
+    model = train_host.GaussianParams(scene, torch.device("cpu"))
+    opt = train_host.make_optimizer(model)
+    assert model.flat.numel() == 257 * 161  # 161 floats per Gaussian at M = 48
+    # every parameter and gradient is a view into the two flat buffers
+    for p in model.params.values():
+        assert p.untyped_storage().data_ptr() == model.flat.untyped_storage().data_ptr()
+        assert p.grad.untyped_storage().data_ptr() == model.flat_grad.untyped_storage().data_ptr()
+    for step in range(3):
+        model.zero_grad()
+        # a rank-dependent "loss" over the activated parameters, through autograd like the real step
+        g = torch.Generator().manual_seed(100 * step + rank)
+        loss = 0.0
+        for name in ("get_xyz", "get_scaling", "get_rotation", "get_opacity", "get_features", "get_t", "get_scaling_t",
+                     "get_rotation_r"):
+            v = getattr(model, name)
+            loss = loss + (v * torch.randn(v.shape, generator=g)).sum()
+        loss.backward()
+        local = model.flat_grad.clone()
+        train_host.allreduce_gradients(model, world)
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        expect = sum(gathered) / world
+        assert torch.allclose(model.flat_grad, expect, rtol=0, atol=1e-6)
+        opt.step()
+        flats = [torch.zeros_like(model.flat) for _ in range(world)]
+        dist.all_gather(flats, model.flat.detach())
+        assert torch.equal(flats[0], flats[1]), "replicas diverged"
+    q.put((rank, float(model.flat.detach().abs().sum())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_bucket_allreduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res[0] == res[1]
