@@ -27,8 +27,16 @@ def test_render_dict_and_gradients(gpu_device):
     assert pkg["render"].shape == (3, H, W) and pkg["depth"].shape == (1, H, W) and pkg["alpha"].shape == (1, H, W)
     assert pkg["flow"].shape == (2, H, W) and pkg["radii"].shape == (P,) and pkg["radii"].dtype == torch.int32
     assert pkg["visibility_filter"].dtype == torch.bool and pkg["viewspace_points"].shape == (P, 3)
-    ref, _ = run_oracle(scene, None, kind="port")
+    # the oracle must see exactly what the rasterizer saw: the model's post-activation tensors
+    osc = dict(scene)
+    osc.update(means3D=model.get_xyz.detach().cpu(), opacities=model.get_opacity.detach().cpu(),
+               scales=model.get_scaling.detach().cpu(), rotations=model.get_rotation.detach().cpu(),
+               scales_t=model.get_scaling_t.detach().cpu(), ts=model.get_t.detach().cpu(),
+               rotations_r=model.get_rotation_r.detach().cpu(), shs=model.get_features.detach().cpu())
+    ref, _ = run_oracle(osc, None, kind="port")
+    assert ref["border_g"].sum() == 0
     ok = ~ref["border"].astype(bool)
+    assert np.array_equal(pkg["radii"].cpu().numpy(), ref["radii"])
     assert np.abs(pkg["render"].detach().cpu().numpy() - ref["out_color"])[:, ok].max() <= 1e-4
     assert np.abs(pkg["alpha"].detach().cpu().numpy()[0] - (1.0 - ref["out_T"]))[ok].max() <= 1e-4
     (pkg["render"].mean() + 0.1 * pkg["depth"].mean() + 0.1 * pkg["alpha"].mean()).backward()

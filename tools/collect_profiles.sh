@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of bench.py plus two separate PMC passes
+# (FETCH_SIZE, WRITE_SIZE) of the rasterizer-only loop, summarised into gpurun_out/profiles_<tag>/.
+set -uo pipefail
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --steps 30 --warmup 10 --cpu-samples 0 > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python $REPO/tools/quick_time.py C3 5 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python $REPO/tools/quick_time.py C3 5 > $OUT/pmc_write.log 2>&1
+cd $REPO
+python tools/pmc_traffic.py $OUT/stats $OUT/fetch $OUT/write $OUT/pmc_traffic_$TAG
+tail -1 $OUT/bench_under_rocprof.log | cut -c1-600
+# keep only the summaries (raw traces are large)
+rm -rf $OUT/fetch/*/*kernel_trace.csv $OUT/write/*/*kernel_trace.csv 2>/dev/null
+ls -la $OUT
