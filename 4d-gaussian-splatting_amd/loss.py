@@ -1,0 +1,53 @@
+"""Fused photometric loss (1 - lambda) L1 + lambda (1 - SSIM) on the GPU (csrc/ssim.hip).
+
+Drop-in for the reference's ``(1.0 - opt.lambda_dssim) * l1_loss(image, gt) + opt.lambda_dssim * (1.0 - ssim(image, gt))``
+(train.py:115-117, utils/loss_utils.py:17-64).  One forward kernel and one backward kernel instead of five
+grouped 11x11 convolutions and their autograd graph.  ``gt`` is treated as a constant (no gradient), as in
+training.  There is no CPU path: CPU tensors raise.  ``fdgs.train_host.photometric_loss`` is the PyTorch
+statement of the same loss, used as the reference in the tests.
+"""
+import torch
+
+from . import _capi
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, lambda_dssim):
+        if not img.is_cuda or not gt.is_cuda:
+            raise RuntimeError("fdgs: fused_l1_ssim needs GPU tensors; there is no CPU path")
+        img_c, gt_c = img.contiguous().float(), gt.contiguous().float()
+        C, H, W = img_c.shape[-3], img_c.shape[-2], img_c.shape[-1]
+        dev = img_c.device
+        d1, d2, d3 = (torch.empty_like(img_c) for _ in range(3))
+        nparts = _capi.lib.fdgs_l1_ssim_num_partials(C, H, W)
+        parts = torch.empty((2, nparts), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_l1_ssim_forward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
+                                                d3.data_ptr(), parts[0].data_ptr(), parts[1].data_ptr(),
+                                                _capi.current_stream_handle(dev))
+        _capi._check(rc, "fdgs_l1_ssim_forward")
+        sums = parts.sum(dim=1) / float(C * H * W)
+        ctx.save_for_backward(img_c, gt_c, d1, d2, d3)
+        ctx.lambda_dssim = float(lambda_dssim)
+        ctx.shape = img.shape
+        return (1.0 - lambda_dssim) * sums[0] + lambda_dssim * (1.0 - sums[1])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img_c, gt_c, d1, d2, d3 = ctx.saved_tensors
+        C, H, W = img_c.shape[-3], img_c.shape[-2], img_c.shape[-1]
+        dev = img_c.device
+        up = grad_out.reshape(1).contiguous().float()
+        g = torch.empty_like(img_c)
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_l1_ssim_backward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
+                                                 d3.data_ptr(), up.data_ptr(), ctx.lambda_dssim, g.data_ptr(),
+                                                 _capi.current_stream_handle(dev))
+        _capi._check(rc, "fdgs_l1_ssim_backward")
+        return g.view(ctx.shape), None, None
+
+
+def fused_l1_ssim(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """(1 - lambda) * L1(image, gt) + lambda * (1 - SSIM(image, gt)); image, gt: [3, H, W] on the GPU."""
+    return _FusedL1SSIM.apply(image, gt, lambda_dssim)

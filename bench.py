@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-loss", action="store_true", help="debug: sum() loss instead of L1 + SSIM")
+    ap.add_argument("--torch-loss", action="store_true", help="L1 + SSIM through PyTorch conv2d (MIOpen) instead of the fused HIP kernel")
     return ap.parse_args()
 
 
@@ -136,6 +137,7 @@ def main():
 
     from fdgs import _capi, synth, train_host
     from fdgs.gaussian_renderer import render
+    from fdgs.loss import fused_l1_ssim
 
     cfg = synth.CONFIGS[args.workload]
     scene = synth.make_scene(cfg, seed=0)
@@ -151,7 +153,12 @@ def main():
     def step():
         model.zero_grad()
         pkg = render(cam, model, pipe, bg)
-        loss = pkg["render"].sum() * 1e-6 if args.no_loss else train_host.photometric_loss(pkg["render"], gt)
+        if args.no_loss:
+            loss = pkg["render"].sum() * 1e-6
+        elif args.torch_loss:
+            loss = train_host.photometric_loss(pkg["render"], gt)
+        else:
+            loss = fused_l1_ssim(pkg["render"], gt, 0.2)
         loss.backward()
         train_host.allreduce_gradients(model, world)
         opt.step()
@@ -217,8 +224,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
-                               "1 view/GPU/step, L1+SSIM loss, Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
-                                                                        M, cfg.rot_4d),
+                               "1 view/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
+                                                                        M, cfg.rot_4d, "PyTorch" if args.torch_loss else "fused HIP"),
                    "num_rendered": R, "visible": Pv, "parallelism": "frame-parallel dp%d" % world},
         "forward_mpix_s": round(world * args.steps * N / dt_fwd / 1e6, 1),
         "forward_ms": round(dt_fwd / args.steps * 1e3, 4),

@@ -205,6 +205,20 @@ int fdgs_profile_read(int stage, double* total_ms, int64_t* samples);
 int fdgs_profile_reset(void);
 const char* fdgs_stage_name(int stage);
 
+/* ---- adjacent row: fused photometric loss ----------------------------
+ * (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM(img, gt)), the reference's loss
+ * (train.py:115-117, utils/loss_utils.py:17-64: 11x11 Gaussian window, sigma 1.5, zero padding).
+ * forward writes three per-pixel derivative maps [C,H,W] (kept for backward) and per-tile partial sums
+ * of |img-gt| and ssim (fdgs_l1_ssim_num_partials entries each; the host adds them up).
+ * backward writes dL/dimg [C,H,W] given the upstream scalar gradient (device pointer). */
+int fdgs_l1_ssim_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                         float* dm_dmu1, float* dm_de11, float* dm_de12,
+                         float* partial_l1, float* partial_ssim, void* stream);
+int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                          const float* dm_dmu1, const float* dm_de11, const float* dm_de12,
+                          const float* upstream, float lambda_dssim, float* dL_dimg, void* stream);
+int fdgs_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W);
+
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* fdgs_last_error(void);
 int fdgs_version(void);
