@@ -1,0 +1,101 @@
+// adam.hip -- fused Adam over the flat parameter bucket (gfx950).
+//
+// The optimizer step that closes every training iteration (reference train.py:247-249,
+// torch.optim.Adam(lr=0, eps=1e-15) over 9 parameter groups, scene/gaussian_model.py:336-353).
+// Parameters, gradients and both moments live in four flat fp32 buffers (161 floats per Gaussian
+// at M = 48), so the whole step is ONE streaming pass: read p, g, m, v, write p, m, v
+// (28 B / element -> 1.35 GB at 300 k Gaussians; PyTorch's multi-tensor path takes 11 launches).
+// Learning rates come from a small segment table; a segment may give its first `head` elements
+// of every `period` a different rate (SH DC vs. rest inside one [P, M, 3] tensor, so the
+// reference's cat(features_dc, features_rest) disappears from the step).
+// Same arithmetic as torch.optim.Adam (no amsgrad / weight decay):
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+#include <algorithm>
+#include <cmath>
+#include "fdgs_common.h"
+
+namespace fdgs
+{
+	constexpr int ADAM_MAX_SEG = 16;
+	struct AdamSegs
+	{
+		long long begin[ADAM_MAX_SEG], end[ADAM_MAX_SEG];
+		float lr[ADAM_MAX_SEG], lr_head[ADAM_MAX_SEG];
+		int period[ADAM_MAX_SEG], head[ADAM_MAX_SEG];
+		int n;
+	};
+
+	__device__ __forceinline__ float seg_lr(const AdamSegs& s, long long i)
+	{
+		float lr = 0.f;
+#pragma unroll 1
+		for (int k = 0; k < s.n; k++)
+			if (i >= s.begin[k] && i < s.end[k])
+			{
+				lr = s.lr[k];
+				if (s.period[k] > 0 && (int)((i - s.begin[k]) % s.period[k]) < s.head[k]) lr = s.lr_head[k];
+			}
+		return lr;
+	}
+
+	__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+	                                                 float* __restrict__ m, float* __restrict__ v, long long n,
+	                                                 const AdamSegs segs, float b1, float b2, float eps,
+	                                                 float inv_bc1, float inv_sqrt_bc2)
+	{
+		const long long nvec = n / 4;
+		const long long stride = (long long)gridDim.x * blockDim.x;
+		for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nvec; q += stride)
+		{
+			const float4 gg = reinterpret_cast<const float4*>(g)[q];
+			float4 mm = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q], pp = reinterpret_cast<float4*>(p)[q];
+			const float ge[4] = { gg.x, gg.y, gg.z, gg.w };
+			float me[4] = { mm.x, mm.y, mm.z, mm.w }, ve[4] = { vv.x, vv.y, vv.z, vv.w }, pe[4] = { pp.x, pp.y, pp.z, pp.w };
+#pragma unroll
+			for (int e = 0; e < 4; e++)
+			{
+				const float lr = seg_lr(segs, 4 * q + e);
+				me[e] = b1 * me[e] + (1.f - b1) * ge[e];
+				ve[e] = b2 * ve[e] + (1.f - b2) * ge[e] * ge[e];
+				const float denom = sqrtf(ve[e]) * inv_sqrt_bc2 + eps;
+				pe[e] -= (lr * inv_bc1) * (me[e] / denom);
+			}
+			reinterpret_cast<float4*>(m)[q] = make_float4(me[0], me[1], me[2], me[3]);
+			reinterpret_cast<float4*>(v)[q] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+			reinterpret_cast<float4*>(p)[q] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+		}
+		// tail (n not a multiple of 4)
+		for (long long i = nvec * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		{
+			const float lr = seg_lr(segs, i);
+			const float gi = g[i];
+			const float mi = b1 * m[i] + (1.f - b1) * gi;
+			const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+			m[i] = mi; v[i] = vi;
+			p[i] -= (lr * inv_bc1) * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+		}
+	}
+}
+
+extern "C" int fdgs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const fdgs_adam_segment* segments, int32_t num_segments,
+                              float beta1, float beta2, float eps, int32_t step, void* stream)
+{
+	using namespace fdgs;
+	if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || !segments || num_segments <= 0 || num_segments > ADAM_MAX_SEG || step < 1)
+		return FDGS_ERR_INVALID_ARG;
+	if (n == 0) return FDGS_OK;
+	AdamSegs s;
+	s.n = num_segments;
+	for (int k = 0; k < num_segments; k++)
+	{
+		s.begin[k] = segments[k].begin; s.end[k] = segments[k].end;
+		s.lr[k] = segments[k].lr; s.lr_head[k] = segments[k].lr_head;
+		s.period[k] = segments[k].period; s.head[k] = segments[k].head;
+	}
+	const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+	const int blocks = (int)std::min<long long>((n / 4 + 255) / 256 + 1, 256 * 16);
+	hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+	                   (long long)n, s, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
+}

@@ -8,9 +8,10 @@ and the RCCL bench share:
 
 * ``GaussianParams``  -- the reference's parameter set and activations
   (scene/gaussian_model.py:179-219: exp scales, sigmoid opacity, normalised
-  quaternions, ``cat(features_dc, features_rest)``), duck-typed for ``render()``.
-  All parameters are views into ONE flat fp32 buffer and all gradients into ONE
-  flat gradient buffer, so the data-parallel exchange is a single collective.
+  quaternions), duck-typed for ``render()``.  All parameters are views into ONE flat
+  fp32 buffer and all gradients into ONE flat gradient buffer, so the data-parallel
+  exchange is a single collective and the optimizer step a single kernel.
+* ``FlatAdam``        -- Adam over that bucket (fused HIP kernel on the GPU).
 * ``allreduce_gradients`` -- one ``all_reduce(SUM)`` over the flat gradient bucket
   (161 floats per Gaussian at M = 48 -> 193 MB at 300 k Gaussians), then the 1/world
   scale of ``loss / batch_size`` (train.py:162).  Frames / timesteps are independent
@@ -30,32 +31,40 @@ def _inv_sigmoid(x):
 
 
 class GaussianParams:
-    """Flat-bucket parameter set with the reference model's getters (post-activation)."""
+    """Flat-bucket parameter set with the reference model's getters (post-activation).
 
-    NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_t", "_scaling_t",
-             "_rotation_r")
+    Differences from scene/gaussian_model.py that do not change the mathematics: the SH coefficients are ONE
+    ``[P, M, 3]`` parameter (the reference keeps ``_features_dc`` / ``_features_rest`` and concatenates them in
+    ``get_features`` every call, :211-215); their two learning rates (feature_lr and feature_lr / 20) are
+    applied per coefficient by the optimizer's segment table instead.
+    """
+
+    NAMES = ("_xyz", "_features", "_opacity", "_scaling", "_rotation", "_t", "_scaling_t", "_rotation_r")
 
     def __init__(self, scene: Dict[str, object], device):
         """``scene``: post-activation tensors from fdgs.synth.make_scene; raw parameters are their inverses."""
         P, M = int(scene["means3D"].shape[0]), int(scene["M"])
-        shapes = {"_xyz": (P, 3), "_features_dc": (P, 1, 3), "_features_rest": (P, M - 1, 3), "_opacity": (P, 1),
-                  "_scaling": (P, 3), "_rotation": (P, 4), "_t": (P, 1), "_scaling_t": (P, 1), "_rotation_r": (P, 4)}
-        init = {"_xyz": scene["means3D"], "_features_dc": scene["shs"][:, :1, :], "_features_rest": scene["shs"][:, 1:, :],
+        shapes = {"_xyz": (P, 3), "_features": (P, M, 3), "_opacity": (P, 1), "_scaling": (P, 3), "_rotation": (P, 4),
+                  "_t": (P, 1), "_scaling_t": (P, 1), "_rotation_r": (P, 4)}
+        init = {"_xyz": scene["means3D"], "_features": scene["shs"],
                 "_opacity": _inv_sigmoid(scene["opacities"].clamp(1e-6, 1 - 1e-6)), "_scaling": torch.log(scene["scales"]),
                 "_rotation": scene["rotations"], "_t": scene["ts"], "_scaling_t": torch.log(scene["scales_t"]),
                 "_rotation_r": scene["rotations_r"]}
-        total = sum(int(torch.tensor(s).prod()) for s in shapes.values())
+        sizes = {n: int(torch.tensor(shapes[n]).prod()) for n in self.NAMES}
+        total = sum(sizes.values())
         self.flat = torch.empty(total, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.params: Dict[str, torch.Tensor] = {}
+        self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
         for name in self.NAMES:
-            n = int(torch.tensor(shapes[name]).prod())
+            n = sizes[name]
             view = self.flat[off:off + n].view(shapes[name])
             view.copy_(init[name].to(device).reshape(shapes[name]))
             p = view.requires_grad_(True)
             p.grad = self.flat_grad[off:off + n].view(shapes[name])
             self.params[name] = p
+            self.offsets[name] = (off, off + n)
             off += n
         self.P, self.M = P, M
         self.active_sh_degree = int(scene["sh_degree"])
@@ -75,25 +84,81 @@ class GaussianParams:
     get_rotation = property(lambda s: F.normalize(s.params["_rotation"]))
     get_rotation_r = property(lambda s: F.normalize(s.params["_rotation_r"]))
     get_opacity = property(lambda s: torch.sigmoid(s.params["_opacity"]))
-    get_features = property(lambda s: torch.cat((s.params["_features_dc"], s.params["_features_rest"]), dim=1))
+    get_features = property(lambda s: s.params["_features"])
 
-    def optimizer_groups(self) -> List[dict]:
-        """Learning rates of arguments/__init__.py:84-92 (spatial_lr_scale = 1)."""
-        lr = {"_xyz": 1.6e-4, "_features_dc": 2.5e-3, "_features_rest": 2.5e-3 / 20.0, "_opacity": 5e-2, "_scaling": 5e-3,
-              "_rotation": 1e-3, "_t": 1.6e-4, "_scaling_t": 5e-3, "_rotation_r": 1e-3}
-        return [{"params": [self.params[n]], "lr": lr[n], "name": n} for n in self.NAMES]
+    def lr_segments(self) -> List[dict]:
+        """Learning rates of arguments/__init__.py:84-92 (spatial_lr_scale = 1) as a segment table."""
+        lr = {"_xyz": 1.6e-4, "_opacity": 5e-2, "_scaling": 5e-3, "_rotation": 1e-3, "_t": 1.6e-4, "_scaling_t": 5e-3,
+              "_rotation_r": 1e-3}
+        segs = []
+        for n in self.NAMES:
+            b, e = self.offsets[n]
+            if n == "_features":  # DC coefficient: feature_lr; the rest: feature_lr / 20
+                segs.append(dict(begin=b, end=e, lr=2.5e-3 / 20.0, lr_head=2.5e-3, period=self.M * 3, head=3))
+            else:
+                segs.append(dict(begin=b, end=e, lr=lr[n], lr_head=lr[n], period=0, head=0))
+        return segs
 
     def zero_grad(self):
         self.flat_grad.zero_()
 
 
-def make_optimizer(model: GaussianParams) -> torch.optim.Optimizer:
-    """torch.optim.Adam(lr=0, eps=1e-15) as scene/gaussian_model.py:353; fused/foreach where the device supports it."""
-    groups = model.optimizer_groups()
-    try:
-        return torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=model.flat.is_cuda)
-    except (RuntimeError, TypeError):
-        return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+class FlatAdam:
+    """torch.optim.Adam(lr=0, eps=1e-15) semantics (scene/gaussian_model.py:353) over the flat bucket.
+
+    On the GPU the step is one fused HIP kernel (csrc/adam.hip, fdgs_adam_step); on the CPU (gloo tests) the same
+    arithmetic in a few PyTorch ops with a per-element learning-rate vector -- also the reference the GPU test
+    compares the kernel against."""
+
+    def __init__(self, model: GaussianParams, betas=(0.9, 0.999), eps=1e-15):
+        self.model, self.betas, self.eps = model, betas, eps
+        self.exp_avg = torch.zeros_like(model.flat)
+        self.exp_avg_sq = torch.zeros_like(model.flat)
+        self.step_count = 0
+        self.segments = model.lr_segments()
+        self._native = None
+        self._lr_vec = None
+
+    def lr_vector(self) -> torch.Tensor:
+        lr = torch.zeros_like(self.model.flat)
+        for s in self.segments:
+            lr[s["begin"]:s["end"]] = s["lr"]
+            if s["period"] > 0:
+                seg = lr[s["begin"]:s["end"]].view(-1, s["period"])
+                seg[:, :s["head"]] = s["lr_head"]
+        return lr
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        m = self.model
+        if m.flat.is_cuda:
+            from . import _capi
+            if self._native is None:
+                arr = (_capi.FdgsAdamSegment * len(self.segments))()
+                for i, s in enumerate(self.segments):
+                    arr[i] = _capi.FdgsAdamSegment(s["begin"], s["end"], s["lr"], s["lr_head"], s["period"], s["head"])
+                self._native = arr
+            with torch.cuda.device(m.flat.device):
+                rc = _capi.lib.fdgs_adam_step(m.flat.data_ptr(), m.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), m.flat.numel(), self._native,
+                                              len(self.segments), self.betas[0], self.betas[1], self.eps,
+                                              self.step_count, _capi.current_stream_handle(m.flat.device))
+            _capi._check(rc, "fdgs_adam_step")
+            return
+        if self._lr_vec is None:
+            self._lr_vec = self.lr_vector()
+        b1, b2 = self.betas
+        g = m.flat_grad
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+        denom = self.exp_avg_sq.sqrt().div_(math.sqrt(bc2)).add_(self.eps)
+        m.flat.sub_(self._lr_vec / bc1 * (self.exp_avg / denom))
+
+
+def make_optimizer(model: GaussianParams) -> FlatAdam:
+    return FlatAdam(model)
 
 
 def allreduce_gradients(model: GaussianParams, world_size: int) -> None:

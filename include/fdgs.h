@@ -219,6 +219,21 @@ int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t 
                           const float* upstream, float lambda_dssim, float* dL_dimg, void* stream);
 int fdgs_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W);
 
+/* ---- adjacent row: fused Adam over a flat parameter bucket ---------
+ * torch.optim.Adam arithmetic (no amsgrad / weight decay) in one streaming pass over four flat fp32
+ * buffers.  Learning rates come from `segments`: elements [begin, end) use `lr`, except that when
+ * period > 0 the first `head` elements of every `period` use `lr_head` (SH DC vs. rest inside one
+ * [P, M, 3] tensor).  Elements outside every segment are left with lr = 0 (moments still update). */
+typedef struct fdgs_adam_segment
+{
+	int64_t begin, end;
+	float lr, lr_head;
+	int32_t period, head;
+} fdgs_adam_segment;
+int fdgs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const fdgs_adam_segment* segments, int32_t num_segments,
+                   float beta1, float beta2, float eps, int32_t step, void* stream);
+
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* fdgs_last_error(void);
 int fdgs_version(void);
