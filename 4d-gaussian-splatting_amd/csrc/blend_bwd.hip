@@ -80,11 +80,12 @@ namespace fdgs
 		float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
 		float* __restrict__ dL_dcolors, float* __restrict__ dL_dflows)
 	{
-		__shared__ float4 s_a[WAVE];
-		__shared__ float4 s_b[WAVE];
-		__shared__ float4 s_c[WAVE];
-		__shared__ uint32_t s_pos[WAVE];
-		__shared__ uint32_t s_id[WAVE];
+		// wave-private queue of the surviving entries of the current chunk (+1: inert padding entry for the prefetch)
+		__shared__ float4 s_a[WAVE + 1];
+		__shared__ float4 s_b[WAVE + 1];
+		__shared__ float4 s_c[WAVE + 1];
+		__shared__ uint32_t s_pos[WAVE + 1];
+		__shared__ uint32_t s_id[WAVE + 1];
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -170,66 +171,77 @@ namespace fdgs
 				s_pos[q] = (uint32_t)pos;
 				s_id[q] = id;
 			}
+			if (lane == 0)
+			{
+				// inert entry behind the queue so the prefetch of entry j+1 never reads stale data
+				s_a[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_b[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_c[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_pos[cnt] = 0x7fffffffu;
+				s_id[cnt] = 0u;
+			}
 			__syncthreads();
 
+			float4 na = s_a[0], nb = s_b[0], nc = s_c[0];
+			uint32_t npos = s_pos[0], nid = s_id[0];
 			for (int j = 0; j < cnt; j++)
 			{
+				// software pipeline: entry j is in registers, entry j+1 is fetched now and lands while j is processed
+				const float4 ea = na, eb = nb, ec = nc;
+				const uint32_t epos = npos, eid = nid;
+				na = s_a[j + 1]; nb = s_b[j + 1]; nc = s_c[j + 1];
+				npos = s_pos[j + 1]; nid = s_id[j + 1];
+
 				float g[16];
 #pragma unroll
 				for (int k = 0; k < 16; k++) g[k] = 0.f;
-				bool active = (int)s_pos[j] < last_contributor;
+				const float dx = ea.x - pixfx, dy = ea.y - pixfy;
+				const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
+				const float G = fast_exp(power);
+				const float alpha = fminf(0.99f, eb.y * G);
+				// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
+				const bool active = ((int)epos < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 				if (active)
 				{
-					const float4 ea = s_a[j];
-					const float4 eb = s_b[j];
-					const float dx = ea.x - pixfx, dy = ea.y - pixfy;
-					const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-					const float G = fast_exp(power);
-					const float alpha = fminf(0.99f, eb.y * G);
-					active = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-					if (active)
-					{
-						const float4 ec = s_c[j];
-						const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-						T = T * inv;
-						const float dchannel_dcolor = alpha * T;
-						float dL_dalpha = 0.0f;
-						const float one_m_la = 1.f - last_alpha;
-						acc0 = last_alpha * lc0 + one_m_la * acc0; lc0 = eb.z; dL_dalpha += (eb.z - acc0) * dLp0;
-						acc1 = last_alpha * lc1 + one_m_la * acc1; lc1 = eb.w; dL_dalpha += (eb.w - acc1) * dLp1;
-						acc2 = last_alpha * lc2 + one_m_la * acc2; lc2 = ec.x; dL_dalpha += (ec.x - acc2) * dLp2;
-						accf0 = last_alpha * lf0 + one_m_la * accf0; lf0 = ec.z; dL_dalpha += (ec.z - accf0) * dLf0;
-						accf1 = last_alpha * lf1 + one_m_la * accf1; lf1 = ec.w; dL_dalpha += (ec.w - accf1) * dLf1;
-						acc_depth = last_alpha * last_depth + one_m_la * acc_depth; last_depth = ec.y;
-						dL_dalpha += (ec.y - acc_depth) * dL_depth;
-						acc_mask = last_alpha + one_m_la * acc_mask;
-						dL_dalpha += (1.0f - acc_mask) * dL_mask;
-						dL_dalpha *= T;
-						last_alpha = alpha;
-						dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
+					const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+					T = T * inv;
+					const float dchannel_dcolor = alpha * T;
+					float dL_dalpha = 0.0f;
+					const float one_m_la = 1.f - last_alpha;
+					acc0 = last_alpha * lc0 + one_m_la * acc0; lc0 = eb.z; dL_dalpha += (eb.z - acc0) * dLp0;
+					acc1 = last_alpha * lc1 + one_m_la * acc1; lc1 = eb.w; dL_dalpha += (eb.w - acc1) * dLp1;
+					acc2 = last_alpha * lc2 + one_m_la * acc2; lc2 = ec.x; dL_dalpha += (ec.x - acc2) * dLp2;
+					accf0 = last_alpha * lf0 + one_m_la * accf0; lf0 = ec.z; dL_dalpha += (ec.z - accf0) * dLf0;
+					accf1 = last_alpha * lf1 + one_m_la * accf1; lf1 = ec.w; dL_dalpha += (ec.w - accf1) * dLf1;
+					acc_depth = last_alpha * last_depth + one_m_la * acc_depth; last_depth = ec.y;
+					dL_dalpha += (ec.y - acc_depth) * dL_depth;
+					acc_mask = last_alpha + one_m_la * acc_mask;
+					dL_dalpha += (1.0f - acc_mask) * dL_mask;
+					dL_dalpha *= T;
+					last_alpha = alpha;
+					dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
 
-						const float dL_dG = eb.y * dL_dalpha;
-						const float gdx = G * dx, gdy = G * dy;
-						const float dG_ddelx = -gdx * ea.z - gdy * ea.w;
-						const float dG_ddely = -gdy * eb.x - gdx * ea.w;
-						g[0] = dchannel_dcolor * dLp0;
-						g[1] = dchannel_dcolor * dLp1;
-						g[2] = dchannel_dcolor * dLp2;
-						g[3] = dchannel_dcolor * dLf0;
-						g[4] = dchannel_dcolor * dLf1;
-						g[5] = dL_dG * dG_ddelx * ddelx_dx;
-						g[6] = dL_dG * dG_ddely * ddely_dy;
-						g[7] = dL_depth * dchannel_dcolor;
-						g[8] = -0.5f * gdx * dx * dL_dG;
-						g[9] = -0.5f * gdx * dy * dL_dG;
-						g[10] = -0.5f * gdy * dy * dL_dG;
-						g[11] = G * dL_dalpha;
-					}
+					const float dL_dG = eb.y * dL_dalpha;
+					const float gdx = G * dx, gdy = G * dy;
+					const float dG_ddelx = -gdx * ea.z - gdy * ea.w;
+					const float dG_ddely = -gdy * eb.x - gdx * ea.w;
+					g[0] = dchannel_dcolor * dLp0;
+					g[1] = dchannel_dcolor * dLp1;
+					g[2] = dchannel_dcolor * dLp2;
+					g[3] = dchannel_dcolor * dLf0;
+					g[4] = dchannel_dcolor * dLf1;
+					g[5] = dL_dG * dG_ddelx * ddelx_dx;
+					g[6] = dL_dG * dG_ddely * ddely_dy;
+					g[7] = dL_depth * dchannel_dcolor;
+					g[8] = -0.5f * gdx * dx * dL_dG;
+					g[9] = -0.5f * gdx * dy * dL_dG;
+					g[10] = -0.5f * gdy * dy * dL_dG;
+					g[11] = G * dL_dalpha;
 				}
 				if (__ballot(active) != 0ull)
 				{
 					const float total = transpose_reduce16(g, lane);
-					if (slot_writer) atomicAdd(slot_ptr + (size_t)s_id[j] * slot_stride, total);
+					if (slot_writer) atomicAdd(slot_ptr + (size_t)eid * slot_stride, total);
 				}
 			}
 			__syncthreads();

@@ -22,10 +22,11 @@ namespace fdgs
 		float* __restrict__ out_color, float* __restrict__ out_flow, float* __restrict__ out_depth, float* __restrict__ out_T,
 		float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 	{
-		__shared__ float4 s_a[WAVE];
-		__shared__ float4 s_b[WAVE];
-		__shared__ float4 s_c[WAVE];
-		__shared__ uint32_t s_pos[WAVE];
+		// wave-private queue of the surviving entries of the current 64-entry chunk (+2: inert padding entry)
+		__shared__ float4 s_a[WAVE + 2];
+		__shared__ float4 s_b[WAVE + 2];
+		__shared__ float4 s_c[WAVE + 2];
+		__shared__ uint32_t s_pos[WAVE + 2];
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -72,28 +73,45 @@ namespace fdgs
 				s_c[slot] = records[3 * (size_t)id + 2];
 				s_pos[slot] = (uint32_t)pos;
 			}
+			if (lane == 0 && (cnt & 1))
+			{
+				// inert padding so the 2x unrolled loop below needs no tail: opacity 0 -> alpha 0 -> rejected
+				s_a[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_b[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_c[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_pos[cnt] = 0u;
+			}
 			__syncthreads(); // single-wave workgroup: orders the LDS writes before the cross-lane reads
 
-			for (int j = 0; j < cnt; j++)
+			// Branch-free inner loop, two entries per trip with all LDS reads issued up front: a wave's
+			// progress here is bound by its dependent-latency chain (LDS -> exp -> compares), not by issue
+			// rate, so the per-pixel tests of the reference (forward.cu:582-597) become predicates + selects.
+			for (int j = 0; j < cnt; j += 2)
 			{
+				const float4 a0 = s_a[j], b0 = s_b[j], c0 = s_c[j];
+				const float4 a1 = s_a[j + 1], b1 = s_b[j + 1], c1 = s_c[j + 1];
+				const uint32_t p0 = s_pos[j], p1 = s_pos[j + 1];
+#define FDGS_BLEND_ONE(ea, eb, ec, epos)                                                                  \
+				{                                                                                         \
+					const float dx = ea.x - pixfx, dy = ea.y - pixfy;                                     \
+					const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;      \
+					const float alpha = fminf(0.99f, eb.y * fast_exp(power));                             \
+					const float test_T = T * (1.0f - alpha);                                              \
+					const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);             \
+					const bool stop = valid && (test_T < 0.0001f);                                        \
+					const bool contrib = valid && !stop;                                                  \
+					const float w = contrib ? alpha * T : 0.0f;                                           \
+					C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;                                       \
+					D += ec.y * w;                                                                        \
+					F0 += ec.z * w; F1 += ec.w * w;                                                       \
+					T = contrib ? test_T : T;                                                             \
+					last_contributor = contrib ? epos + 1u : last_contributor;                            \
+					done = done || stop;                                                                  \
+				}
+				FDGS_BLEND_ONE(a0, b0, c0, p0)
+				FDGS_BLEND_ONE(a1, b1, c1, p1)
+#undef FDGS_BLEND_ONE
 				if (__ballot(!done) == 0ull) break;
-				if (done) continue;
-				const float4 ea = s_a[j];
-				const float4 eb = s_b[j];
-				const float dx = ea.x - pixfx, dy = ea.y - pixfy;
-				const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-				if (power > 0.0f) continue;
-				const float alpha = fminf(0.99f, eb.y * fast_exp(power));
-				if (alpha < 1.0f / 255.0f) continue;
-				const float test_T = T * (1.0f - alpha);
-				if (test_T < 0.0001f) { done = true; continue; }
-				const float4 ec = s_c[j];
-				const float w = alpha * T;
-				C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;
-				D += ec.y * w;
-				F0 += ec.z * w; F1 += ec.w * w;
-				T = test_T;
-				last_contributor = s_pos[j] + 1u;
 			}
 			__syncthreads(); // the queue is rewritten by the next chunk
 		}
