@@ -17,8 +17,10 @@
 //     half of its slots and hands the other half to its partner, so after 4 steps
 //     each lane of a 16-lane row owns ONE fully row-reduced slot (24+12+12+3 VALU ops
 //     instead of 12 x 6), two cross-row shuffles finish the sum, and lanes 0..15 then
-//     issue ONE global_atomic_add_f32 instruction for the 12 live slots;
-//   => 12 atomic lane-ops per surviving (block, Gaussian) instead of 12 per (pixel, Gaussian).
+//     issue ONE global_atomic_add_f32 instruction for the 12 live slots, all inside the Gaussian's
+//     packed 64-byte accumulator record (one cache line = one memory-side atomic request);
+//   => one atomic request per surviving (block, Gaussian) instead of 12 per (pixel, Gaussian).
+//   preprocess_bwd unpacks the records into the user-visible gradient tensors.
 #include "blend_common.h"
 
 namespace fdgs
@@ -77,8 +79,7 @@ namespace fdgs
 		const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
 		const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_masks,
 		const float* __restrict__ dL_dpix_flow,
-		float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic2D, float* __restrict__ dL_dopacity,
-		float* __restrict__ dL_dcolors, float* __restrict__ dL_dflows)
+		float* __restrict__ gacc)
 	{
 		// wave-private queue of the surviving entries of the current chunk (+1: inert padding entry for the prefetch)
 		__shared__ float4 s_a[WAVE + 1];
@@ -121,26 +122,13 @@ namespace fdgs
 		const float bg_dot_dpixel = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
 		const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H; // backward.cu:1010-1011
 
-		// where the slot this lane owns after transpose_reduce16 goes: 12 live slots in lanes 0..15
+		// The slot this lane owns after transpose_reduce16 (12 live slots in lanes 0..15) is word `slot` of the
+		// Gaussian's packed 64-byte accumulator record: colour 0-2, flow 3-4, mean2D 5-7, conic xx/xy/yy 8-10,
+		// opacity 11.  One record = one cache line, so the 12-lane atomic instruction is ONE memory-side
+		// request instead of five (device-scope float atomics are RMWs at the memory side on this chip and
+		// their request rate, not the VALU, bounds this kernel).
 		const int slot = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-		float* slot_ptr = nullptr;
-		int slot_stride = 0;
-		switch (slot)
-		{
-		case 0: slot_ptr = dL_dcolors + 0; slot_stride = 3; break;
-		case 1: slot_ptr = dL_dcolors + 1; slot_stride = 3; break;
-		case 2: slot_ptr = dL_dcolors + 2; slot_stride = 3; break;
-		case 3: slot_ptr = dL_dflows + 0; slot_stride = 2; break;
-		case 4: slot_ptr = dL_dflows + 1; slot_stride = 2; break;
-		case 5: slot_ptr = dL_dmean2D + 0; slot_stride = 3; break;
-		case 6: slot_ptr = dL_dmean2D + 1; slot_stride = 3; break;
-		case 7: slot_ptr = dL_dmean2D + 2; slot_stride = 3; break;
-		case 8: slot_ptr = dL_dconic2D + 0; slot_stride = 4; break;
-		case 9: slot_ptr = dL_dconic2D + 1; slot_stride = 4; break;
-		case 10: slot_ptr = dL_dconic2D + 3; slot_stride = 4; break;
-		case 11: slot_ptr = dL_dopacity; slot_stride = 1; break;
-		default: break;
-		}
+		float* const slot_ptr = gacc + slot;
 		const bool slot_writer = lane < 16 && slot < NG;
 
 		float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accf0 = 0.f, accf1 = 0.f, acc_depth = 0.f, acc_mask = 0.f;
@@ -241,7 +229,7 @@ namespace fdgs
 				if (__ballot(active) != 0ull)
 				{
 					const float total = transpose_reduce16(g, lane);
-					if (slot_writer) atomicAdd(slot_ptr + (size_t)eid * slot_stride, total);
+					if (slot_writer) atomicAdd(slot_ptr + (size_t)eid * GRAD_ACC_WORDS, total);
 				}
 			}
 			__syncthreads();
@@ -258,7 +246,7 @@ namespace fdgs
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records),
 		                   s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib,
 		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow,
-		                   out.dL_dmeans2D, out.dL_dconic, out.dL_dopacity, out.dL_dcolors, out.dL_dflows);
+		                   out.grad_accum);
 		return hipGetLastError();
 	}
 }

@@ -255,7 +255,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	    !in->radii || !in->out_means3D || !in->geom_buffer || !in->binning_buffer || !in->image_buffer)
 		return fail(FDGS_ERR_INVALID_ARG, "backward inputs must not be NULL");
 	if (!out->dL_dmeans2D || !out->dL_dcolors || !out->dL_dopacity || !out->dL_dmeans3D || !out->dL_dcov3D ||
-	    !out->dL_dflows || !out->dL_dconic || (s.shs && !out->dL_dsh))
+	    !out->dL_dflows || !out->grad_accum || (s.shs && !out->dL_dsh))
 		return fail(FDGS_ERR_INVALID_ARG, "backward outputs must not be NULL");
 	if (s.cov3D_precomp == nullptr)
 	{
@@ -274,12 +274,8 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	const int tres = final_buf(tile_sort_passes(T));
 	const uint32_t* point_list = (const uint32_t*)(bin + BL.val[tres]);
 
-	// the five atomically-accumulated per-Gaussian gradients start from zero
-	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dmeans2D, 0, (size_t)P * 12, stream), "memset");
-	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dconic, 0, (size_t)P * 16, stream), "memset");
-	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dopacity, 0, (size_t)P * 4, stream), "memset");
-	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dcolors, 0, (size_t)P * 12, stream), "memset");
-	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->dL_dflows, 0, (size_t)P * 8, stream), "memset");
+	// the packed accumulator records of the blend backward start from zero
+	STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->grad_accum, 0, (size_t)P * GRAD_ACC_WORDS * 4, stream), "memset");
 
 	if (R > 0)
 		STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),

@@ -18,7 +18,8 @@ namespace fdgs
 	constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
 	constexpr int RADIX_BITS = 8;
 	constexpr int RADIX = 1 << RADIX_BITS;
-	constexpr int SCAN_CHUNK = 4096;    // elements per workgroup in the 3-phase scan
+	constexpr int SCAN_CHUNK = 4096;
+	constexpr int GRAD_ACC_WORDS = 16;  // packed per-Gaussian gradient accumulator record (64 B = one cache line)    // elements per workgroup in the 3-phase scan
 
 	static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 	static inline int div_up(int a, int b) { return (a + b - 1) / b; }

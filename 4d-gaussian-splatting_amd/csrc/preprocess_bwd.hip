@@ -34,7 +34,8 @@ namespace fdgs
 		int rot_4d, gaussian_dim, force_sh_3d;
 		const int32_t* radii; const float* means; /* out_means3D */
 		const float* cov3D; const uint8_t* clamped;
-		const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor;
+		const float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
+		float *dL_dmean2D, *dL_dcolor, *dL_dflows;
 		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dsh, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
 	};
 
@@ -230,6 +231,14 @@ namespace fdgs
 		float4 drot = make_float4(0, 0, 0, 0), drot_r = make_float4(0, 0, 0, 0);
 		const int n_sh_floats = a.shs ? a.M * 3 : 0;
 		float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * n_sh_floats : nullptr;
+		// unpack the accumulator record: colour 0-2, flow 3-4, mean2D 5-7, conic xx/xy/yy 8-10, opacity 11
+		const float4* rec = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS);
+		const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+		const float3 g_color = make_float3(r0.x, r0.y, r0.z);
+		const float2 g_flow = make_float2(r0.w, r1.x);
+		const float3 g_mean2D = make_float3(r1.y, r1.z, r1.w);
+		const float3 g_conic = make_float3(r2.x, r2.y, r2.z);
+		float g_opacity = r2.w;
 
 		if (!visible)
 		{
@@ -245,8 +254,7 @@ namespace fdgs
 
 			// ---------------- cov2D backward (backward.cu:486-617) ----------------
 			{
-				const float4 dcon = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
-				const float dcx = dcon.x, dcy = dcon.y, dcz = dcon.w;
+				const float dcx = g_conic.x, dcy = g_conic.y, dcz = g_conic.z;
 				const Cov2D p = project_cov(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.viewmatrix);
 				const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
 				const float x_grad_mul = (p.txtz < -limx || p.txtz > limx) ? 0.f : 1.f;
@@ -288,7 +296,7 @@ namespace fdgs
 				const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
 				const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
 				const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * p.t.x) * tz3 * dL_dJ02 + (2 * h_y * p.t.y) * tz3 * dL_dJ12;
-				const float vz = dL_dtz + a.dL_dmean2D[3 * (size_t)idx + 2]; // Q10: depth-gradient carrier
+				const float vz = dL_dtz + g_mean2D.z; // Q10: depth-gradient carrier
 				const float* m = a.viewmatrix; // transformVec4x3Transpose, auxiliary.h:90-98
 				dmean.x = m[0] * dL_dtx + m[1] * dL_dty + m[2] * vz;
 				dmean.y = m[4] * dL_dtx + m[5] * dL_dty + m[6] * vz;
@@ -302,7 +310,7 @@ namespace fdgs
 				const float m_w = 1.0f / (m_hom.w + 0.0000001f);
 				const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
 				const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-				const float gx = a.dL_dmean2D[3 * (size_t)idx], gy = a.dL_dmean2D[3 * (size_t)idx + 1];
+				const float gx = g_mean2D.x, gy = g_mean2D.y;
 				dmean.x += (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
 				dmean.y += (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
 				dmean.z += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
@@ -315,7 +323,7 @@ namespace fdgs
 				const float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z); // Q4
 				const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
 				const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-				float3 dRGB = b_ld3(a.dL_dcolor, idx);
+				float3 dRGB = g_color;
 				const uint8_t cl = a.clamped[idx];
 				if (cl & 1) dRGB.x = 0.f;
 				if (cl & 2) dRGB.y = 0.f;
@@ -370,9 +378,8 @@ namespace fdgs
 						float dL_dcovt = (c12[0] * c12[0] * dcov[0] + c12[0] * c12[1] * dcov[1] +
 						                  c12[0] * c12[2] * dcov[2] + c12[1] * c12[1] * dcov[3] +
 						                  c12[1] * c12[2] * dcov[4] + c12[2] * c12[2] * dcov[5]) / (cov_t * cov_t);
-						const float dop = a.dL_dopacity[idx];
-						const float dL_dmarginal_t = dop * a.opacities[idx];
-						a.dL_dopacity[idx] = dop * marginal_t;
+						const float dL_dmarginal_t = g_opacity * a.opacities[idx];
+						g_opacity *= marginal_t;
 						const float dmarg_dcovt = marginal_t * dt * dt / 2 / (cov_t_pre * cov_t_pre);
 						const float dmarg_dt = marginal_t * dt / cov_t_pre;
 						dL_dcovt += dmarg_dcovt * dL_dmarginal_t;
@@ -462,6 +469,10 @@ namespace fdgs
 		}
 
 		// ---- stores (every output written for every Gaussian) ----
+		b_st3(a.dL_dmean2D, idx, g_mean2D);
+		b_st3(a.dL_dcolor, idx, g_color);
+		a.dL_dflows[2 * (size_t)idx] = g_flow.x; a.dL_dflows[2 * (size_t)idx + 1] = g_flow.y;
+		a.dL_dopacity[idx] = g_opacity;
 		b_st3(a.dL_dmeans, idx, dmean);
 #pragma unroll
 		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
@@ -490,7 +501,8 @@ namespace fdgs
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.cov3D = reinterpret_cast<const float*>(geom + L.cov3D);
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
-		a.dL_dmean2D = out.dL_dmeans2D; a.dL_dconic = out.dL_dconic; a.dL_dcolor = out.dL_dcolors;
+		a.gacc = out.grad_accum;
+		a.dL_dmean2D = out.dL_dmeans2D; a.dL_dcolor = out.dL_dcolors; a.dL_dflows = out.dL_dflows;
 		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
 		a.dL_dsh = s.shs ? out.dL_dsh : nullptr;
 		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;

@@ -141,7 +141,7 @@ class _NativeRasterizer:
             "dL_dflows": torch.empty((P, 2), **fo), "dL_dts": torch.empty((P, 1), **fo),
             "dL_dscales": torch.empty((P, 3), **fo), "dL_dscales_t": torch.empty((P, 1), **fo),
             "dL_drotations": torch.empty((P, 4), **fo), "dL_drotations_r": torch.empty((P, 4), **fo),
-            "dL_dconic": torch.empty((P, 2, 2), **fo),
+            "grad_accum": torch.empty((P, 16), **fo),  # packed blend-backward accumulators (scratch)
         }
         gin = [_capi._dev_f32(t, n) for t, n in ((dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"),
                                                  (dL_dout_mask, "dL_dout_mask"), (dL_dout_flow, "dL_dout_flow"))]
@@ -151,7 +151,7 @@ class _NativeRasterizer:
                                     _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R))
         bout = _capi.FdgsBackwardOut(*[_capi._ptr(g[k]) for k in (
             "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
-            "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r", "dL_dconic")])
+            "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r", "grad_accum")])
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
                                                    _capi.current_stream_handle(dev))

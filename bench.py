@@ -46,7 +46,7 @@ ALGO_BYTES = {
     "emit_instances": lambda P, Pv, M, R, N, T: 8 * R + 16 * P,
     "offset_scan": lambda P, Pv, M, R, N, T: 20 * P,
     "tile_ranges": lambda P, Pv, M, R, N, T: 4 * R + 16 * T,
-    "grad_zero": lambda P, Pv, M, R, N, T: 52 * P,
+    "grad_zero": lambda P, Pv, M, R, N, T: 64 * P,
 }
 
 

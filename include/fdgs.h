@@ -141,7 +141,8 @@ typedef struct fdgs_backward_out
 	float* dL_dscales_t;    /* [P]                                                 */
 	float* dL_drotations;   /* [P,4]                                               */
 	float* dL_drotations_r; /* [P,4]                                               */
-	float* dL_dconic;       /* [P,4]  scratch for the 2D conic gradient (Q12 layout) */
+	float* grad_accum;      /* [P,16] scratch: packed per-Gaussian accumulators of the blend backward
+	                           (colour 3, flow 2, mean2D 3, conic xx/xy/yy 3 (Q12 convention), opacity 1, pad 4) */
 } fdgs_backward_out;
 
 /* Forward pass: preprocess -> depth sort -> scan -> instance emission -> tile
