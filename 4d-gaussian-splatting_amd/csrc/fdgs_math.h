@@ -97,6 +97,22 @@ namespace fdgs
 		return R;
 	}
 
+	// The reference model's activations (scene/gaussian_model.py:55-66, 179-219), used when fdgs_scene.raw_params != 0
+	__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+	__device__ __forceinline__ float4 act_normalize(const float4 v, float* inv_norm)
+	{
+		const float n = sqrtf((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+		const float inv = 1.0f / fmaxf(n, 1e-12f); // F.normalize eps
+		*inv_norm = inv;
+		return make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+	}
+	// d/dv of v / |v| applied to g:  (g - q (q . g)) / |v|
+	__device__ __forceinline__ float4 act_normalize_bwd(const float4 q, float inv_norm, const float4 g)
+	{
+		const float d = (q.x * g.x + q.y * g.y) + (q.z * g.z + q.w * g.w);
+		return make_float4((g.x - q.x * d) * inv_norm, (g.y - q.y * d) * inv_norm, (g.z - q.z * d) * inv_norm, (g.w - q.w * d) * inv_norm);
+	}
+
 	// SH constants (reference auxiliary.h:23-40)
 	__device__ constexpr float SH_C0 = 0.28209479177387814f;
 	__device__ constexpr float SH_C1 = 0.4886025119029199f;

@@ -31,7 +31,7 @@ namespace fdgs
 		const float *shs, *opacities, *ts, *scales, *scales_t, *rotations, *rotations_r, *cov3D_precomp;
 		const float *viewmatrix, *projmatrix, *campos;
 		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
-		int rot_4d, gaussian_dim, force_sh_3d;
+		int rot_4d, gaussian_dim, force_sh_3d, raw;
 		const int32_t* radii; const float* means; /* out_means3D */
 		const float* cov3D; const uint8_t* clamped;
 		const float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
@@ -353,15 +353,30 @@ namespace fdgs
 			if (a.scales)
 			{
 				const float mod = a.scale_modifier;
-				const float3 sc = b_ld3(a.scales, idx);
+				float3 sc = b_ld3(a.scales, idx);
+				float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+				float inv_nq = 1.f, inv_nqr = 1.f;
+				if (a.raw)
+				{
+					sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+					q = act_normalize(q, &inv_nq);
+				}
 				if (a.rot_4d)
 				{
 					// backward.cu:689-834
-					const float scale_t = a.scales_t[idx];
+					float scale_t = a.scales_t[idx];
+					float4 qr = reinterpret_cast<const float4*>(a.rotations_r)[idx];
+					float opac = a.opacities[idx];
+					if (a.raw)
+					{
+						scale_t = expf(scale_t);
+						qr = act_normalize(qr, &inv_nqr);
+						opac = act_sigmoid(opac);
+					}
 					const float dt = a.timestamp - a.ts[idx];
 					const M4 S = diag4(mod * sc.x, mod * sc.y, mod * sc.z, mod * scale_t);
 					M4 Ml, Mr;
-					build_Ml_Mr(reinterpret_cast<const float4*>(a.rotations)[idx], reinterpret_cast<const float4*>(a.rotations_r)[idx], Ml, Mr);
+					build_Ml_Mr(q, qr, Ml, Mr);
 					const M4 R = mul(Mr, Ml);
 					const M4 M = mul(S, R);
 					const M4 Sigma = mul(transpose(M), M);
@@ -378,7 +393,7 @@ namespace fdgs
 						float dL_dcovt = (c12[0] * c12[0] * dcov[0] + c12[0] * c12[1] * dcov[1] +
 						                  c12[0] * c12[2] * dcov[2] + c12[1] * c12[1] * dcov[3] +
 						                  c12[1] * c12[2] * dcov[4] + c12[2] * c12[2] * dcov[5]) / (cov_t * cov_t);
-						const float dL_dmarginal_t = g_opacity * a.opacities[idx];
+						const float dL_dmarginal_t = g_opacity * opac;
 						g_opacity *= marginal_t;
 						const float dmarg_dcovt = marginal_t * dt * dt / 2 / (cov_t_pre * cov_t_pre);
 						const float dmarg_dt = marginal_t * dt / cov_t_pre;
@@ -422,12 +437,16 @@ namespace fdgs
 						drot_r.y = -B.c[0][1] + B.c[1][0] + B.c[2][3] - B.c[3][2];
 						drot_r.z = B.c[0][2] + B.c[1][3] - B.c[2][0] - B.c[3][1];
 						drot_r.w = B.c[0][3] - B.c[1][2] + B.c[2][1] - B.c[3][0];
+						if (a.raw)
+						{
+							dscale_t *= scale_t;                       // d exp
+							drot_r = act_normalize_bwd(qr, inv_nqr, drot_r);
+						}
 					}
 				}
 				else
 				{
 					// backward.cu:621-684
-					const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
 					const float r = q.x, x = q.y, y = q.z, z = q.w;
 					const M3 R = quat_to_R(q);
 					const float s3[3] = { mod * sc.x, mod * sc.y, mod * sc.z };
@@ -465,9 +484,20 @@ namespace fdgs
 #undef DD
 					// Q6: gaussian_dim == 4 without rot_4d has no marginal-opacity backward
 				}
+				if (a.raw)
+				{
+					dscale = make_float3(dscale.x * sc.x, dscale.y * sc.y, dscale.z * sc.z); // d exp
+					drot = act_normalize_bwd(q, inv_nq, drot);
+				}
 			}
 		}
 
+		if (a.raw)
+		{
+			// d sigmoid: the blend accumulated dL/d(activated opacity) (already rescaled by marginal_t where rot_4d)
+			const float o = act_sigmoid(a.opacities[idx]);
+			g_opacity *= o * (1.0f - o);
+		}
 		// ---- stores (every output written for every Gaussian) ----
 		b_st3(a.dL_dmean2D, idx, g_mean2D);
 		b_st3(a.dL_dcolor, idx, g_color);
@@ -497,7 +527,7 @@ namespace fdgs
 		a.focal_y = s.H / (2.0f * s.tan_fovy); // rasterizer_impl.cu:424-425
 		a.focal_x = s.W / (2.0f * s.tan_fovx);
 		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
-		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.raw = s.raw_params;
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.cov3D = reinterpret_cast<const float*>(geom + L.cov3D);
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);

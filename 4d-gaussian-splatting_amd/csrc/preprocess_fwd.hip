@@ -30,7 +30,7 @@ namespace fdgs
 		const float *means3D, *shs, *colors_precomp, *flows, *opacities, *ts, *scales, *scales_t;
 		const float *rotations, *rotations_r, *cov3D_precomp, *viewmatrix, *projmatrix, *campos;
 		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
-		int rot_4d, gaussian_dim, force_sh_3d;
+		int rot_4d, gaussian_dim, force_sh_3d, raw;
 		int grid_x, grid_y;
 		// outputs
 		int32_t* radii; float* out_means3D; float* covs_com;
@@ -147,6 +147,7 @@ namespace fdgs
 		float3 p_orig = ld3(a.means3D, idx);
 		const float3 p_in = p_orig;
 		float opacity = a.opacities[idx];
+		if (a.raw) opacity = act_sigmoid(opacity);
 		float cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 		bool alive = true;
 
@@ -158,12 +159,22 @@ namespace fdgs
 		else if (a.rot_4d)
 		{
 			// forward.cu:279-352
-			const float3 sc = ld3(a.scales, idx);
+			float3 sc = ld3(a.scales, idx);
+			float sct = a.scales_t[idx];
+			float4 q = reinterpret_cast<const float4*>(a.rotations)[idx], qr = reinterpret_cast<const float4*>(a.rotations_r)[idx];
+			if (a.raw)
+			{
+				float unused;
+				sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+				sct = expf(sct);
+				q = act_normalize(q, &unused);
+				qr = act_normalize(qr, &unused);
+			}
 			const float mod = a.scale_modifier;
 			const float dt = a.timestamp - a.ts[idx];
-			const M4 S = diag4(mod * sc.x, mod * sc.y, mod * sc.z, mod * a.scales_t[idx]);
+			const M4 S = diag4(mod * sc.x, mod * sc.y, mod * sc.z, mod * sct);
 			M4 Ml, Mr;
-			build_Ml_Mr(reinterpret_cast<const float4*>(a.rotations)[idx], reinterpret_cast<const float4*>(a.rotations_r)[idx], Ml, Mr);
+			build_Ml_Mr(q, qr, Ml, Mr);
 			const M4 M = mul(S, mul(Mr, Ml));
 			const M4 Sigma = mul(transpose(M), M);
 			const float cov_t = Sigma.c[3][3];
@@ -187,7 +198,14 @@ namespace fdgs
 		else
 		{
 			// forward.cu:242-276
-			const float3 sc = ld3(a.scales, idx);
+			float3 sc = ld3(a.scales, idx);
+			float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+			if (a.raw)
+			{
+				float unused;
+				sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+				q = act_normalize(q, &unused);
+			}
 			const float mod = a.scale_modifier;
 			M3 S;
 #pragma unroll
@@ -195,7 +213,7 @@ namespace fdgs
 #pragma unroll
 				for (int i = 0; i < 3; i++) S.c[j][i] = 0.0f;
 			S.c[0][0] = mod * sc.x; S.c[1][1] = mod * sc.y; S.c[2][2] = mod * sc.z;
-			const M3 M = mul(S, quat_to_R(reinterpret_cast<const float4*>(a.rotations)[idx]));
+			const M3 M = mul(S, quat_to_R(q));
 			const M3 Sigma = mul(transpose(M), M);
 			cov[0] = Sigma.c[0][0]; cov[1] = Sigma.c[0][1]; cov[2] = Sigma.c[0][2];
 			cov[3] = Sigma.c[1][1]; cov[4] = Sigma.c[1][2]; cov[5] = Sigma.c[2][2];
@@ -203,7 +221,7 @@ namespace fdgs
 			{
 				// forward.cu:431-437 (scales_t used as a variance)
 				const float dt = a.ts[idx] - a.timestamp;
-				const float sigma = a.scales_t[idx] * mod;
+				const float sigma = (a.raw ? expf(a.scales_t[idx]) : a.scales_t[idx]) * mod;
 				const float marginal_t = expf((float)(-0.5 * dt * dt / ((a.prefilter_var > 0.0) ? (a.prefilter_var + sigma) : sigma)));
 				if (marginal_t <= 0.05) alive = false;
 				else opacity *= marginal_t;
@@ -319,7 +337,7 @@ namespace fdgs
 		a.focal_y = s.H / (2.0f * s.tan_fovy); // rasterizer_impl.cu:235-236
 		a.focal_x = s.W / (2.0f * s.tan_fovx);
 		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
-		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.raw = s.raw_params;
 		a.grid_x = div_up(s.W, TILE_X); a.grid_y = div_up(s.H, TILE_Y);
 		a.radii = out.radii; a.out_means3D = out.out_means3D; a.covs_com = out.covs_com;
 		a.records = reinterpret_cast<float4*>(geom + L.records);

@@ -56,7 +56,7 @@ class _NativeRasterizer:
     @staticmethod
     def _scene(bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r, scale_modifier,
                cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, degree_t,
-               campos, timestamp, time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug):
+               campos, timestamp, time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug, raw_params=False):
         if means3D.ndim != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:69-71
         f = _capi._dev_f32
@@ -81,20 +81,23 @@ class _NativeRasterizer:
         s.timestamp, s.time_duration = float(timestamp), float(time_duration)
         s.rot_4d, s.gaussian_dim, s.force_sh_3d = int(bool(rot_4d)), int(gaussian_dim), int(bool(force_sh_3d))
         s.prefiltered, s.debug = int(bool(prefiltered)), int(bool(debug))
+        s.raw_params = int(bool(raw_params))
         return s, keep
 
     def rasterize_gaussians(self, bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
                             scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
-                            gaussian_dim, force_sh_3d, prefiltered, debug):
-        """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49)."""
+                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False):
+        """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49).
+        ``raw_params`` (keyword-only extension): the scale / opacity / rotation tensors are the model's raw
+        parameters and the kernels apply the activations (fdgs_scene.raw_params)."""
         if not means3D.is_cuda:
             raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
         dev = means3D.device
         scene, keep = self._scene(bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
                                   scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx,
                                   tan_fovy, image_height, image_width, sh, degree, degree_t, campos, timestamp,
-                                  time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug)
+                                  time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug, raw_params)
         P, H, W = scene.P, scene.H, scene.W
         fo = dict(dtype=torch.float32, device=dev)
         # every output is fully written by the kernels: torch.empty, not torch.full (rasterize_points.cu:80-85)
@@ -123,14 +126,17 @@ class _NativeRasterizer:
                                      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
-                                     imageBuffer, debug):
-        """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89)."""
+                                     imageBuffer, debug, *, raw_params=False, grad_out=None):
+        """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
+        Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
+        (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
+        preallocated contiguous tensors the kernels write into (e.g. views of a flat gradient bucket)."""
         dev = means3D.device
         H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])  # rasterize_points.cu:192-193
         scene, keep = self._scene(bg, means3D, colors, flows_2d, opacities, ts, scales, scales_t, rotations,
                                   rotations_r, scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix,
                                   tan_fovx, tan_fovy, H, W, sh, degree, degree_t, campos, timestamp, time_duration,
-                                  rot_4d, gaussian_dim, force_sh_3d, False, debug)
+                                  rot_4d, gaussian_dim, force_sh_3d, False, debug, raw_params)
         P, M = scene.P, scene.M
         fo = dict(dtype=torch.float32, device=dev)
         # fully written by the kernels (the reference zero-fills all 13 with torch::zeros, rasterize_points.cu:201-213)
@@ -143,6 +149,14 @@ class _NativeRasterizer:
             "dL_drotations": torch.empty((P, 4), **fo), "dL_drotations_r": torch.empty((P, 4), **fo),
             "grad_accum": torch.empty((P, 16), **fo),  # packed blend-backward accumulators (scratch)
         }
+        if grad_out:
+            for name, t in grad_out.items():
+                if t is None:
+                    continue
+                if name not in g or t.numel() != g[name].numel() or not t.is_contiguous() or t.dtype != torch.float32:
+                    raise RuntimeError("fdgs: grad_out[%r] must be a contiguous float32 tensor with %d elements" %
+                                       (name, g[name].numel() if name in g else -1))
+                g[name] = t
         gin = [_capi._dev_f32(t, n) for t, n in ((dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"),
                                                  (dL_dout_mask, "dL_dout_mask"), (dL_dout_flow, "dL_dout_flow"))]
         radii_c, om_c = radii.contiguous(), out_means3D.contiguous()

@@ -64,6 +64,7 @@ class GaussianParams:
             p = view.requires_grad_(True)
             p.grad = self.flat_grad[off:off + n].view(shapes[name])
             self.params[name] = p
+            setattr(self, name, p)  # the reference's attribute names (scene/gaussian_model.py:70-80)
             self.offsets[name] = (off, off + n)
             off += n
         self.P, self.M = P, M
@@ -101,6 +102,14 @@ class GaussianParams:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def grad_sink(self) -> Dict[str, torch.Tensor]:
+        """Gradient destinations for fdgs.fused.render_raw: the rasterizer backward writes each parameter's
+        gradient straight into its slice of the flat bucket (no autograd accumulation pass, no zero_grad)."""
+        g = {n: self.params[n].grad for n in self.NAMES}
+        return {"dL_dmeans3D": g["_xyz"], "dL_dsh": g["_features"], "dL_dopacity": g["_opacity"],
+                "dL_dscales": g["_scaling"], "dL_drotations": g["_rotation"], "dL_dts": g["_t"],
+                "dL_dscales_t": g["_scaling_t"], "dL_drotations_r": g["_rotation_r"]}
 
 
 class FlatAdam:

@@ -4,8 +4,9 @@ C3 workload (300 k 4D Gaussians, 1352x1014, SH degree 3 + time degree 2 (M = 48)
 
 One *step* = one pass of the hot path over one view per rank, structured like the reference's
 training iteration (train.py:104-166, 247-249):
-    activations (exp / sigmoid / normalize / cat, PyTorch) -> render() forward (HIP) ->
-    (1-l) L1 + l (1 - SSIM) (PyTorch) -> backward (HIP + autograd) ->
+    activations (exp / sigmoid / normalize; fused into the preprocess kernels, --reference-host: PyTorch) ->
+    render forward (HIP) -> (1-l) L1 + l (1 - SSIM) (fused HIP kernel, --torch-loss: PyTorch conv2d) ->
+    backward (HIP; gradients land directly in the flat bucket) ->
     [N > 1: ONE all-reduce of the flat 161*P-float gradient bucket over RCCL] -> Adam step.
 Frames / timesteps shard embarrassingly: rank r renders timestamp (r + 0.5) / N of the sequence with
 replicated parameters (scaling = "weak": one view per GPU per step).  Inputs are synthetic
@@ -58,6 +59,8 @@ def parse_args():
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-loss", action="store_true", help="debug: sum() loss instead of L1 + SSIM")
+    ap.add_argument("--reference-host", action="store_true",
+                    help="host side exactly as the reference: render() on PyTorch activations, autograd gradient accumulation")
     ap.add_argument("--torch-loss", action="store_true", help="L1 + SSIM through PyTorch conv2d (MIOpen) instead of the fused HIP kernel")
     return ap.parse_args()
 
@@ -138,6 +141,7 @@ def main():
     from fdgs import _capi, synth, train_host
     from fdgs.gaussian_renderer import render
     from fdgs.loss import fused_l1_ssim
+    from fdgs.fused import render_raw
 
     cfg = synth.CONFIGS[args.workload]
     scene = synth.make_scene(cfg, seed=0)
@@ -150,9 +154,15 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     gt = torch.rand(3, scene["H"], scene["W"], generator=gen).to(dev)
 
+    sink = None if args.reference_host else model.grad_sink()
+
     def step():
-        model.zero_grad()
-        pkg = render(cam, model, pipe, bg)
+        if args.reference_host:
+            model.zero_grad()
+            pkg = render(cam, model, pipe, bg)
+        else:
+            # fused activations + gradients written straight into the flat bucket (every element is overwritten)
+            pkg = render_raw(cam, model, pipe, bg, grad_sink=sink)
         if args.no_loss:
             loss = pkg["render"].sum() * 1e-6
         elif args.torch_loss:
@@ -225,7 +235,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "1 view/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
-                                                                        M, cfg.rot_4d, "PyTorch" if args.torch_loss else "fused HIP"),
+                                                                        M, cfg.rot_4d, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else ", fused activations"),
                    "num_rendered": R, "visible": Pv, "parallelism": "frame-parallel dp%d" % world},
         "forward_mpix_s": round(world * args.steps * N / dt_fwd / 1e6, 1),
         "forward_ms": round(dt_fwd / args.steps * 1e3, 4),

@@ -94,6 +94,12 @@ typedef struct fdgs_scene
 	int32_t rot_4d, gaussian_dim, force_sh_3d;
 	int32_t prefiltered;
 	int32_t debug;        /* != 0: synchronise + check after every stage (CHECK_CUDA, auxiliary.h:165-172) */
+	int32_t raw_params;   /* 0 (reference semantics): scales / scales_t / opacities / rotations / rotations_r are
+	                         post-activation, as the reference passes them.
+	                         1 (fused activations): they are the model's RAW parameters and
+	                         the kernels apply the reference's activations themselves (scene/gaussian_model.py:179-219:
+	                         exp, exp, sigmoid, x / max(|x|, 1e-12) twice); backward then returns gradients w.r.t. the
+	                         raw parameters. */
 } fdgs_scene;
 
 /* Forward outputs; every array is fully written by the call (no pre-zeroing needed). */

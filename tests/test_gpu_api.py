@@ -112,3 +112,46 @@ def test_c3_full_size_properties(gpu_device):
     culled = a["radii"] <= 0
     for k in ("dL_dmean3D", "dL_dscale", "dL_drot", "dL_dsh", "dL_dopacity"):
         assert np.abs(ag[k][culled]).max() == 0.0, k
+
+
+def test_render_raw_matches_render(gpu_device):
+    """Fused activations (fdgs_scene.raw_params): same image / radii as render() with PyTorch activations, and the
+    same parameter gradients as autograd through exp / sigmoid / normalize -- with and without a gradient sink."""
+    from fdgs import train_host
+    from fdgs.fused import render_raw
+    from fdgs.gaussian_renderer import render
+    cfg = synth.SceneConfig("raw", 6000, 208, 160, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=6)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=gpu_device)
+    up = synth.make_upstream_grads(scene["W"], scene["H"], seed=3, scale=1e-2)
+    wc, wd, wa = up["grad_color"].to(gpu_device), up["grad_depth"].to(gpu_device), up["grad_alpha"].to(gpu_device)
+
+    def loss_of(pkg):
+        return (pkg["render"] * wc).sum() + (pkg["depth"] * wd).sum() + (pkg["alpha"] * wa).sum()
+
+    ref_model, cam, pipe = _model_cam(scene, gpu_device)
+    ref_model.zero_grad()
+    ref = render(cam, ref_model, pipe, bg)
+    loss_of(ref).backward()
+    ref_grad = ref_model.flat_grad.clone()
+
+    for use_sink in (False, True):
+        model = train_host.GaussianParams(scene, gpu_device)
+        model.flat_grad.fill_(float("nan") if use_sink else 0.0)  # a sink must be fully overwritten
+        pkg = render_raw(cam, model, pipe, bg, grad_sink=model.grad_sink() if use_sink else None)
+        assert (pkg["radii"] != ref["radii"]).float().mean().item() <= 1e-4
+        d = (pkg["render"] - ref["render"]).abs()
+        assert (d > 1e-4).float().mean().item() <= 1e-4, d.max().item()
+        loss_of(pkg).backward()
+        got = model.flat_grad
+        assert torch.isfinite(got).all()
+        for name, (b, e) in model.offsets.items():
+            r, g = ref_grad[b:e], got[b:e]
+            scale = max(1.0, r.abs().max().item())
+            # in-kernel expf / sigmoid / normalize differ from PyTorch's by an ulp on the activated inputs, which moves a
+            # few alpha ~ 1/255 threshold decisions: bound the fraction of affected elements and the typical error
+            err = (g - r).abs()
+            bad = (err > 2e-4 * scale).float().mean().item()
+            assert bad <= 2e-3, (name, use_sink, err.max().item(), scale)
+            assert err.median().item() <= 1e-5 * scale and err.max().item() <= 1e-2 * scale
+        assert pkg["viewspace_points"].grad is not None
