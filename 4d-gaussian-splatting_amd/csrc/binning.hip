@@ -294,39 +294,66 @@ namespace fdgs
 	// ------------------------------------------------------------------
 	// instance emission: one lane per output slot (coalesced key/value stores)
 	// ------------------------------------------------------------------
-	// Slot s belongs to the depth-ordered Gaussian j with offsets[j] <= s < offsets[j+1]
-	// (binary search; offsets is P*4 bytes and stays in L2).  Within a Gaussian the
-	// slots enumerate its tile rectangle y-major like the reference
-	// (rasterizer_impl.cu:99-109) -- irrelevant for the final order, which only
-	// depends on (tile, depth order), but kept for readability of dumps.
-	__global__ void __launch_bounds__(256) emit_instances_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-	                                                            const ushort4* __restrict__ rect, int P, int R, int grid_x,
-	                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+	// Slot s belongs to the depth-ordered Gaussian j with offsets[j] <= s < offsets[j+1].  A workgroup owns
+	// EMIT_SLOTS consecutive slots: one lane binary-searches the owner of the first slot in global memory, the
+	// workgroup copies the next EMIT_SLOTS+1 offsets (every visible Gaussian owns >= 1 slot, so all owners of
+	// the workgroup's slots are in that window) into LDS, and every lane then searches the LDS window -- 10
+	// LDS steps instead of 18 dependent global loads per slot.  Within a Gaussian the slots enumerate its tile
+	// rectangle y-major like the reference (rasterizer_impl.cu:99-109); the final order only depends on
+	// (tile, depth order).
+	constexpr int EMIT_THREADS = 256;
+	constexpr int EMIT_PER_THREAD = 4;
+	constexpr int EMIT_SLOTS = EMIT_THREADS * EMIT_PER_THREAD;
+
+	__global__ void __launch_bounds__(EMIT_THREADS) emit_instances_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+	                                                                    const ushort4* __restrict__ rect, int P, int R, int grid_x,
+	                                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 	{
-		const int s = blockIdx.x * blockDim.x + threadIdx.x;
-		if (s >= R) return;
-		// largest j with offsets[j] <= s  (offsets is non-decreasing; empty Gaussians share an offset
-		// with their successor, so take the LAST j with offsets[j] <= s)
-		int lo = 0, hi = P - 1;
-		while (lo < hi)
+		__shared__ uint32_t win[EMIT_SLOTS + 1];
+		__shared__ int j0_s;
+		const int s0 = blockIdx.x * EMIT_SLOTS;
+		if (threadIdx.x == 0)
 		{
-			const int mid = (lo + hi + 1) >> 1;
-			if (offsets[mid] <= (uint32_t)s) lo = mid; else hi = mid - 1;
+			// largest j with offsets[j] <= s0 (offsets is non-decreasing; culled Gaussians sit at the end with offset R)
+			int lo = 0, hi = P - 1;
+			while (lo < hi)
+			{
+				const int mid = (lo + hi + 1) >> 1;
+				if (offsets[mid] <= (uint32_t)s0) lo = mid; else hi = mid - 1;
+			}
+			j0_s = lo;
 		}
-		const uint32_t g = order[lo];
-		const ushort4 rc = rect[g];
-		const uint32_t local = (uint32_t)s - offsets[lo];
-		const uint32_t w = (uint32_t)(rc.z - rc.x);
-		const uint32_t ty = rc.y + local / w, tx = rc.x + local % w;
-		keys[s] = ty * (uint32_t)grid_x + tx;
-		vals[s] = g;
+		__syncthreads();
+		const int j0 = j0_s;
+		const int nwin = min(EMIT_SLOTS + 1, P - j0);
+		for (int i = threadIdx.x; i < nwin; i += EMIT_THREADS) win[i] = offsets[j0 + i];
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < EMIT_PER_THREAD; k++)
+		{
+			const int s = s0 + k * EMIT_THREADS + threadIdx.x;
+			if (s >= R) continue;
+			int lo = 0, hi = nwin - 1;
+			while (lo < hi)
+			{
+				const int mid = (lo + hi + 1) >> 1;
+				if (win[mid] <= (uint32_t)s) lo = mid; else hi = mid - 1;
+			}
+			const uint32_t g = order[j0 + lo];
+			const ushort4 rc = rect[g];
+			const uint32_t local = (uint32_t)s - win[lo];
+			const uint32_t w = (uint32_t)(rc.z - rc.x);
+			const uint32_t ty = rc.y + local / w, tx = rc.x + local % w;
+			keys[s] = ty * (uint32_t)grid_x + tx;
+			vals[s] = g;
+		}
 	}
 
 	hipError_t launch_emit_instances(const uint32_t* order, const uint32_t* offsets, const uint16_t* rect,
 	                                 int P, int R, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)
 	{
 		if (R <= 0) return hipSuccess;
-		hipLaunchKernelGGL(emit_instances_kernel, dim3(div_up(R, 256)), dim3(256), 0, stream,
+		hipLaunchKernelGGL(emit_instances_kernel, dim3(div_up(R, EMIT_SLOTS)), dim3(EMIT_THREADS), 0, stream,
 		                   order, offsets, reinterpret_cast<const ushort4*>(rect), P, R, grid_x, keys, vals);
 		return hipGetLastError();
 	}

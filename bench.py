@@ -76,8 +76,14 @@ def init_dist(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if os.environ.get("FDGS_BENCH_DEBUG_SHARE_GPU"):
+            # debug only: exercise the multi-rank control flow on a 1-GPU box (all ranks on cuda:0, gloo collectives)
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     return world, rank, local
 
 
