@@ -7,7 +7,9 @@
 // (forward.cu:198-237), conic, radius, tile rectangle (auxiliary.h:47-57),
 // SH / 4D-SH -> RGB (forward.cu:20-195).
 //
-// What is different from the reference's kernel: it emits ONE packed 48-byte
+// What is different from the reference's kernel: the SH coefficients (12*M bytes per Gaussian, the bulk of
+// the input) are staged per wave through LDS with fully coalesced loads instead of a 12*M-byte stride between
+// threads; culled Gaussians are never fetched.  It emits ONE packed 48-byte
 // blend record per Gaussian (position, conic, opacity, colour, depth, flow)
 // instead of four separate arrays, the tile rectangle (so later stages never
 // recompute it), the depth-sort key/value pair, and it writes every output
@@ -30,7 +32,7 @@ namespace fdgs
 		const float *means3D, *shs, *colors_precomp, *flows, *opacities, *ts, *scales, *scales_t;
 		const float *rotations, *rotations_r, *cov3D_precomp, *viewmatrix, *projmatrix, *campos;
 		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
-		int rot_4d, gaussian_dim, force_sh_3d, raw;
+		int rot_4d, gaussian_dim, force_sh_3d, raw, sh_vec_ok;
 		int grid_x, grid_y;
 		// outputs
 		int32_t* radii; float* out_means3D; float* covs_com;
@@ -108,11 +110,11 @@ namespace fdgs
 		for (int k = lo + 1; k <= hi; k++) acc = add3(acc, scl3(l[k - off], ld3(sh, k)));
 		return acc;
 	}
-	// 4D SH (forward.cu:73-195); time harmonics only when deg > 2
-	__device__ float3 sh_color_4d(int deg, int deg_t, const float* __restrict__ sh, float3 dir, float dir_t, float time_duration)
+	// 4D SH (forward.cu:73-195), split by coefficient block so each block of 16 coefficients can be staged through
+	// LDS on its own: block 0 = the plain SH sum, blocks 1 / 2 = the same basis times cos(2 pi k dt / T), k = 1, 2
+	// (only when deg > 2).  Evaluation order inside and across blocks is the reference's.
+	__device__ __forceinline__ float3 sh4d_block0(int deg, const float* l, const float* __restrict__ sh)
 	{
-		float l[16];
-		sh_basis_4d(deg, dir.x, dir.y, dir.z, l);
 		float3 result = scl3(l[0], ld3(sh, 0));
 		if (deg > 0)
 		{
@@ -120,36 +122,77 @@ namespace fdgs
 			if (deg > 1)
 			{
 				result = add3(result, sh_weighted(l, sh, 4, 8, 0));
-				if (deg > 2)
-				{
-					result = add3(result, sh_weighted(l, sh, 9, 15, 0));
-					if (deg_t > 0)
-					{
-						const float t1 = (float)cos(2 * REF_PI * dir_t / time_duration);
-						result = add3(result, scl3(t1, sh_weighted(l, sh, 16, 31, 16)));
-						if (deg_t > 1)
-						{
-							const float t2 = (float)cos(2 * REF_PI * dir_t * 2 / time_duration);
-							result = add3(result, scl3(t2, sh_weighted(l, sh, 32, 47, 32)));
-						}
-					}
-				}
+				if (deg > 2) result = add3(result, sh_weighted(l, sh, 9, 15, 0));
 			}
 		}
-		return make_float3(result.x + 0.5f, result.y + 0.5f, result.z + 0.5f);
+		return result;
+	}
+
+	// Coalesced staging of one coefficient block of 64 consecutive Gaussians into a wave-private LDS tile
+	// (row stride SH_STRIDE floats: odd, so the lane-per-Gaussian reads that follow are bank-conflict free).
+	// The reference reads these 12*M bytes per Gaussian with a 12*M-byte stride between threads (forward.cu:85).
+	constexpr int SH_STRIDE = 49;
+	// generic path (any coefficient count / alignment): one float per lane and trip
+	__device__ __forceinline__ void stage_sh_block_scalar(float* __restrict__ tile, const float* __restrict__ shs, int g0, int P, int M,
+	                                                      int first_coeff, int ncoeff, unsigned long long alive_mask, int lane)
+	{
+		const int nf = 3 * ncoeff;                 // floats per Gaussian in this block
+		const int total = WAVE * nf;
+		const size_t row_floats = (size_t)3 * M;
+		int g = lane / nf, pos = lane - g * nf;    // element e = lane, lane + 64, ...  ->  (Gaussian, float)
+		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
+		for (int e = lane; e < total; e += WAVE)
+		{
+			if (g0 + g < P && ((alive_mask >> g) & 1ull))
+				tile[g * SH_STRIDE + pos] = shs[(size_t)(g0 + g) * row_floats + (size_t)first_coeff * 3 + pos];
+			g += dg; pos += dpos;
+			if (pos >= nf) { pos -= nf; g++; }
+		}
+	}
+	// full 16-coefficient block, rows 16-byte aligned: each lane issues its 12 dwordx4 loads back to back
+	// (64 lanes x 16 B = 1 KiB per instruction, 192-byte runs), then scatters them into the tile
+	__device__ __forceinline__ void stage_sh_block16(float* __restrict__ tile, const float* __restrict__ shs, int g0, int P, int M,
+	                                                 int first_coeff, unsigned long long alive_mask, int lane)
+	{
+		constexpr int CH = 12;                     // float4 chunks per Gaussian: 16 coefficients x 3 floats / 4
+		const size_t row_floats = (size_t)3 * M;
+		float4 v[CH];
+#pragma unroll
+		for (int i = 0; i < CH; i++)
+		{
+			const int c = i * WAVE + lane, g = c / CH, q = c - g * CH;
+			const bool ok = g0 + g < P && ((alive_mask >> g) & 1ull);
+			v[i] = ok ? *reinterpret_cast<const float4*>(shs + (size_t)(g0 + g) * row_floats + (size_t)first_coeff * 3 + 4 * q)
+			          : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int i = 0; i < CH; i++)
+		{
+			const int c = i * WAVE + lane, g = c / CH, q = c - g * CH;
+			float* d = tile + g * SH_STRIDE + 4 * q;
+			d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+		}
+	}
+	__device__ __forceinline__ void stage_sh_block(float* __restrict__ tile, const float* __restrict__ shs, int g0, int P, int M,
+	                                               int first_coeff, int ncoeff, unsigned long long alive_mask, int lane, bool vec_ok)
+	{
+		if (vec_ok && ncoeff == 16) stage_sh_block16(tile, shs, g0, P, M, first_coeff, alive_mask, lane);
+		else stage_sh_block_scalar(tile, shs, g0, P, M, first_coeff, ncoeff, alive_mask, lane);
 	}
 
 	__global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreArgs a)
 	{
-		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-		if (idx >= a.P) return;
+		// every lane stays until the end: the SH blocks are staged cooperatively per wave
+		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
+		const bool valid = tid_g < a.P;
+		const int idx = valid ? tid_g : a.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
 
 		float3 p_orig = ld3(a.means3D, idx);
 		const float3 p_in = p_orig;
 		float opacity = a.opacities[idx];
 		if (a.raw) opacity = act_sigmoid(opacity);
 		float cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-		bool alive = true;
+		bool alive = valid;
 
 		if (a.cov3D_precomp != nullptr)
 		{
@@ -279,24 +322,54 @@ namespace fdgs
 			}
 		}
 
-		if (alive)
+		if (a.colors_precomp != nullptr)
 		{
-			if (a.colors_precomp != nullptr) rgb = ld3(a.colors_precomp, idx);
-			else
+			if (alive) rgb = ld3(a.colors_precomp, idx);
+		}
+		else
+		{
+			__shared__ float s_sh[256 / WAVE][WAVE * SH_STRIDE];
+			const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+			float* tile = s_sh[wave];
+			const float* row = tile + lane * SH_STRIDE;
+			const unsigned long long amask = __ballot(alive);
+			const int g0 = blockIdx.x * blockDim.x + wave * WAVE;
+			const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
+			const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
+			const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+			// Q4: the forward view direction uses the UN-shifted input mean (forward.cu:480-482)
+			float3 dir = sub3(p_in, make_float3(a.campos[0], a.campos[1], a.campos[2]));
+			const float len = sqrtf(dot3(dir.x, dir.y, dir.z, dir.x, dir.y, dir.z));
+			dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+			float l[16];
+			if (!sh3d) sh_basis_4d(a.D, dir.x, dir.y, dir.z, l);
+			const float dir_t = (!sh3d) ? a.ts[idx] - a.timestamp : 0.f;
+			float3 c = make_float3(0.f, 0.f, 0.f);
+			for (int blk = 0; blk < nblocks; blk++)
 			{
-				// Q4: the forward view direction uses the UN-shifted input mean (forward.cu:480-482)
-				float3 dir = sub3(p_in, make_float3(a.campos[0], a.campos[1], a.campos[2]));
-				const float len = sqrtf(dot3(dir.x, dir.y, dir.z, dir.x, dir.y, dir.z));
-				dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
-				const float* sh = a.shs + (size_t)idx * a.M * 3;
-				float3 c;
-				if (a.gaussian_dim == 3 || a.force_sh_3d) c = sh_color_3d(a.D, sh, dir);
-				else c = sh_color_4d(a.D, a.D_t, sh, dir, a.ts[idx] - a.timestamp, a.time_duration);
+				stage_sh_block(tile, a.shs, g0, a.P, a.M, 16 * blk, blk == 0 ? ncoef0 : 16, amask, lane, a.sh_vec_ok != 0);
+				__syncthreads();
+				if (alive)
+				{
+					if (blk == 0) c = sh3d ? sh_color_3d(a.D, row, dir) : sh4d_block0(a.D, l, row);
+					else
+					{
+						const float tk = (blk == 1) ? (float)cos(2 * REF_PI * dir_t / a.time_duration)
+						                            : (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+						c = add3(c, scl3(tk, sh_weighted(l, row, 0, 15, 0)));
+					}
+				}
+				__syncthreads();
+			}
+			if (alive)
+			{
+				if (!sh3d) c = make_float3(c.x + 0.5f, c.y + 0.5f, c.z + 0.5f); // sh_color_3d already added it
 				clampbits = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
 				rgb = make_float3(fmaxf(c.x, 0.0f), fmaxf(c.y, 0.0f), fmaxf(c.z, 0.0f));
 			}
 		}
 
+		if (!valid) return;
 		// ---- stores (every output written for every Gaussian) ----
 		a.radii[idx] = radius;
 		a.tiles_touched[idx] = tiles;
@@ -338,6 +411,7 @@ namespace fdgs
 		a.focal_x = s.W / (2.0f * s.tan_fovx);
 		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
 		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.raw = s.raw_params;
+		a.sh_vec_ok = (s.shs != nullptr && (reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
 		a.grid_x = div_up(s.W, TILE_X); a.grid_y = div_up(s.H, TILE_Y);
 		a.radii = out.radii; a.out_means3D = out.out_means3D; a.covs_com = out.covs_com;
 		a.records = reinterpret_cast<float4*>(geom + L.records);
