@@ -72,7 +72,7 @@ EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visi
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_last_error", "fdgs_version")
-NUM_STAGES = 10
+NUM_STAGES = 11
 
 
 def _load():

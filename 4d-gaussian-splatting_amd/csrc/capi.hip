@@ -94,7 +94,7 @@ namespace
 		}
 	};
 	const char* const STAGE_NAMES[FDGS_NUM_STAGES] = { "preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
-		"tile_sort", "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero" };
+		"tile_sort", "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero", "sh_bwd" };
 }
 
 extern "C" int fdgs_profile_enable(int on) { g_prof_on.store(on != 0); return FDGS_OK; }
@@ -280,6 +280,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	if (R > 0)
 		STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
 		                       (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
+	STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
 	STAGE(FDGS_STAGE_PREPROCESS_BWD, launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
 	return FDGS_OK;
 }

@@ -126,6 +126,10 @@ namespace fdgs
 	                            const float* records, const uint32_t* point_list, const uint32_t* ranges,
 	                            const float* final_T, const uint32_t* n_contrib, hipStream_t stream);
 
+	// SH / 4D-SH backward (coalesced); must run after the blend backward and before launch_preprocess_bwd
+	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
+	                         const char* geom, hipStream_t stream);
+
 	hipError_t launch_preprocess_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                                 const char* geom, hipStream_t stream);
 

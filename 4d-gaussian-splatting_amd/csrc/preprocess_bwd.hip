@@ -1,11 +1,12 @@
 // preprocess_bwd.hip -- fused per-Gaussian backward (gfx950).
 //
 // One kernel does what the reference does in two (computeCov2DCUDA backward.cu:486-617,
-// then preprocessCUDA backward.cu:839-923 with computeColorFromSH[_4D] :20-481,
-// computeCov3D :621-684, computeCov3D_conditional :689-834): the conic gradient ->
-// cov2D -> cov3D + view-space mean gradient, the projection Jacobian, the SH /
-// 4D-SH backward, and the covariance backward to scales / scale_t / rotations /
-// rotation_r / t, including the marginal-opacity chain.  Fusing keeps dL_dcov3D
+// then preprocessCUDA backward.cu:839-923 with computeCov3D :621-684 and
+// computeCov3D_conditional :689-834): the conic gradient -> cov2D -> cov3D + view-space mean
+// gradient, the projection Jacobian, and the covariance backward to scales / scale_t /
+// rotations / rotation_r / t, including the marginal-opacity chain.  The SH / 4D-SH backward
+// (80 % of the bytes) runs before it as its own coalesced kernel (sh_bwd.hip) and hands over
+// four floats per Gaussian.  Fusing keeps dL_dcov3D
 // and dL_dmean3D in registers between the two halves, and every output is
 // written for every Gaussian (zeros for culled ones), so the caller never
 // pre-zeroes the ~180 floats per Gaussian the reference memsets
@@ -36,7 +37,7 @@ namespace fdgs
 		const float* cov3D; const uint8_t* clamped;
 		const float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
 		float *dL_dmean2D, *dL_dcolor, *dL_dflows;
-		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dsh, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
+		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
 	};
 
 	__device__ __forceinline__ float3 b_ld3(const float* p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -57,166 +58,6 @@ namespace fdgs
 		return r;
 	}
 
-	// 3D SH backward (backward.cu:20-139). Writes dL_dsh[0..(deg+1)^2), returns dL/d(dir).
-	__device__ float3 sh_bwd_3d(int deg, const float* __restrict__ sh, float* __restrict__ dsh, float3 dir, float3 dRGB)
-	{
-		float3 dx = make_float3(0, 0, 0), dy = dx, dz = dx;
-		const float x = dir.x, y = dir.y, z = dir.z;
-		b_st3(dsh, 0, b_scl(SH_C0, dRGB));
-		if (deg > 0)
-		{
-			b_st3(dsh, 1, b_scl(-SH_C1 * y, dRGB));
-			b_st3(dsh, 2, b_scl(SH_C1 * z, dRGB));
-			b_st3(dsh, 3, b_scl(-SH_C1 * x, dRGB));
-			dx = b_scl(-SH_C1, b_ld3(sh, 3));
-			dy = b_scl(-SH_C1, b_ld3(sh, 1));
-			dz = b_scl(SH_C1, b_ld3(sh, 2));
-			if (deg > 1)
-			{
-				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-				b_st3(dsh, 4, b_scl(SH_C2[0] * xy, dRGB));
-				b_st3(dsh, 5, b_scl(SH_C2[1] * yz, dRGB));
-				b_st3(dsh, 6, b_scl(SH_C2[2] * (2.f * zz - xx - yy), dRGB));
-				b_st3(dsh, 7, b_scl(SH_C2[3] * xz, dRGB));
-				b_st3(dsh, 8, b_scl(SH_C2[4] * (xx - yy), dRGB));
-				const float3 s4 = b_ld3(sh, 4), s5 = b_ld3(sh, 5), s6 = b_ld3(sh, 6), s7 = b_ld3(sh, 7), s8 = b_ld3(sh, 8);
-				dx = b_add(dx, b_add(b_add(b_add(b_scl(SH_C2[0] * y, s4), b_scl(SH_C2[2] * 2.f * -x, s6)), b_scl(SH_C2[3] * z, s7)), b_scl(SH_C2[4] * 2.f * x, s8)));
-				dy = b_add(dy, b_add(b_add(b_add(b_scl(SH_C2[0] * x, s4), b_scl(SH_C2[1] * z, s5)), b_scl(SH_C2[2] * 2.f * -y, s6)), b_scl(SH_C2[4] * 2.f * -y, s8)));
-				dz = b_add(dz, b_add(b_add(b_scl(SH_C2[1] * y, s5), b_scl(SH_C2[2] * 2.f * 2.f * z, s6)), b_scl(SH_C2[3] * x, s7)));
-				if (deg > 2)
-				{
-					b_st3(dsh, 9, b_scl(SH_C3[0] * y * (3.f * xx - yy), dRGB));
-					b_st3(dsh, 10, b_scl(SH_C3[1] * xy * z, dRGB));
-					b_st3(dsh, 11, b_scl(SH_C3[2] * y * (4.f * zz - xx - yy), dRGB));
-					b_st3(dsh, 12, b_scl(SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), dRGB));
-					b_st3(dsh, 13, b_scl(SH_C3[4] * x * (4.f * zz - xx - yy), dRGB));
-					b_st3(dsh, 14, b_scl(SH_C3[5] * z * (xx - yy), dRGB));
-					b_st3(dsh, 15, b_scl(SH_C3[6] * x * (xx - 3.f * yy), dRGB));
-					const float3 s9 = b_ld3(sh, 9), s10 = b_ld3(sh, 10), s11 = b_ld3(sh, 11), s12 = b_ld3(sh, 12),
-					             s13 = b_ld3(sh, 13), s14 = b_ld3(sh, 14), s15 = b_ld3(sh, 15);
-					float3 ax = b_scl(SH_C3[0] * 3.f * 2.f * xy, s9);
-					ax = b_add(ax, b_scl(SH_C3[1] * yz, s10));
-					ax = b_add(ax, b_scl(SH_C3[2] * -2.f * xy, s11));
-					ax = b_add(ax, b_scl(SH_C3[3] * -3.f * 2.f * xz, s12));
-					ax = b_add(ax, b_scl(SH_C3[4] * (-3.f * xx + 4.f * zz - yy), s13));
-					ax = b_add(ax, b_scl(SH_C3[5] * 2.f * xz, s14));
-					ax = b_add(ax, b_scl(SH_C3[6] * 3.f * (xx - yy), s15));
-					dx = b_add(dx, ax);
-					float3 ay = b_scl(SH_C3[0] * 3.f * (xx - yy), s9);
-					ay = b_add(ay, b_scl(SH_C3[1] * xz, s10));
-					ay = b_add(ay, b_scl(SH_C3[2] * (-3.f * yy + 4.f * zz - xx), s11));
-					ay = b_add(ay, b_scl(SH_C3[3] * -3.f * 2.f * yz, s12));
-					ay = b_add(ay, b_scl(SH_C3[4] * -2.f * xy, s13));
-					ay = b_add(ay, b_scl(SH_C3[5] * -2.f * yz, s14));
-					ay = b_add(ay, b_scl(SH_C3[6] * -3.f * 2.f * xy, s15));
-					dy = b_add(dy, ay);
-					float3 az = b_scl(SH_C3[1] * xy, s10);
-					az = b_add(az, b_scl(SH_C3[2] * 4.f * 2.f * yz, s11));
-					az = b_add(az, b_scl(SH_C3[3] * 3.f * (2.f * zz - xx - yy), s12));
-					az = b_add(az, b_scl(SH_C3[4] * 4.f * 2.f * xz, s13));
-					az = b_add(az, b_scl(SH_C3[5] * (xx - yy), s14));
-					dz = b_add(dz, az);
-				}
-			}
-		}
-		return make_float3(b_dot(dx, dRGB), b_dot(dy, dRGB), b_dot(dz, dRGB));
-	}
-
-	// 4D SH backward (backward.cu:144-481), bug-compatible.  Returns dL/d(dir); *dL_dt receives the ts gradient.
-	__device__ float3 sh_bwd_4d(int deg, int deg_t, const float* __restrict__ sh, float* __restrict__ dsh, float3 dir, float3 dRGB,
-	                            float dir_t, float time_duration, float* dL_dt)
-	{
-		const float x = dir.x, y = dir.y, z = dir.z;
-		float l[16], dX[16], dY[16], dZ[16];
-#pragma unroll
-		for (int k = 0; k < 16; k++) { l[k] = 0.f; dX[k] = 0.f; dY[k] = 0.f; dZ[k] = 0.f; }
-		l[0] = SH_C0;
-		float3 gx = make_float3(0, 0, 0), gy = gx, gz = gx, gt = gx;
-		b_st3(dsh, 0, b_scl(l[0], dRGB));
-		if (deg > 0)
-		{
-			l[1] = -1 * SH_C1 * y; l[2] = SH_C1 * z; l[3] = -1 * SH_C1 * x;
-			dY[1] = -1 * SH_C1; dZ[2] = SH_C1; dX[3] = -1 * SH_C1;
-			b_st3(dsh, 1, b_scl(l[0], dRGB)); // Q1
-			b_st3(dsh, 2, b_scl(l[2], dRGB));
-			b_st3(dsh, 3, b_scl(l[3], dRGB));
-			gx = b_scl(dX[3], b_ld3(sh, 3));
-			gy = b_scl(dY[1], b_ld3(sh, 1));
-			gz = b_scl(dZ[2], b_ld3(sh, 2));
-			if (deg > 1)
-			{
-				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-				l[4] = SH_C2[0] * xy; l[5] = SH_C2[1] * yz; l[6] = (float)(SH_C2[2] * (2.0 * zz - xx - yy));
-				l[7] = SH_C2[3] * xz; l[8] = SH_C2[4] * (xx - yy);
-				dX[4] = SH_C2[0] * y; dY[4] = SH_C2[0] * x;
-				dY[5] = SH_C2[1] * z; dZ[5] = SH_C2[1] * y;
-				dX[6] = -2 * SH_C2[2] * x; dY[6] = -2 * SH_C2[2] * y; dZ[6] = 4 * SH_C2[2] * z;
-				dX[7] = SH_C2[3] * z; dZ[7] = SH_C2[3] * x;
-				dX[8] = 2 * SH_C2[4] * x; dY[8] = -2 * SH_C2[4] * y;
-				for (int k = 4; k <= 8; k++) b_st3(dsh, k, b_scl(l[k], dRGB));
-				const float3 s4 = b_ld3(sh, 4), s5 = b_ld3(sh, 5), s6 = b_ld3(sh, 6), s7 = b_ld3(sh, 7), s8 = b_ld3(sh, 8);
-				gx = b_add(gx, b_add(b_add(b_add(b_scl(dX[4], s4), b_scl(dX[6], s6)), b_scl(dX[7], s7)), b_scl(dX[8], s8)));
-				gy = b_add(gy, b_add(b_add(b_add(b_scl(dY[4], s4), b_scl(dY[5], s5)), b_scl(dY[6], s6)), b_scl(dY[8], s8)));
-				gz = b_add(gz, b_add(b_add(b_scl(dZ[5], s5), b_scl(dZ[6], s6)), b_scl(dZ[7], s7)));
-				if (deg > 2)
-				{
-					l[9] = SH_C3[0] * y * (3 * xx - yy);
-					l[10] = SH_C3[1] * xy * z;
-					l[11] = SH_C3[2] * y * (4 * zz - xx - yy);
-					l[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
-					l[13] = SH_C3[4] * x * (4 * zz - xx - yy);
-					l[14] = SH_C3[5] * z * (xx - yy);
-					l[15] = SH_C3[6] * x * (xx - 3 * yy);
-					dX[9] = SH_C3[0] * y * 6 * x;               dY[9] = SH_C3[0] * (3 * xx - 3 * yy);
-					dX[10] = SH_C3[1] * yz;                     dY[10] = SH_C3[1] * xz;                     dZ[10] = SH_C3[1] * xy;
-					dX[11] = -SH_C3[2] * y * 2 * x;             dY[11] = SH_C3[2] * (4 * zz - xx - 3 * yy);  dZ[11] = SH_C3[2] * y * 8 * z;
-					dX[12] = -SH_C3[3] * z * 6 * x;             dY[12] = -SH_C3[3] * z * 6 * y;             dZ[12] = SH_C3[3] * (6 * zz - 3 * xx - 3 * yy);
-					dX[13] = SH_C3[4] * (4 * zz - 3 * xx - yy);  dY[13] = -SH_C3[4] * x * 2 * y;             dZ[13] = SH_C3[4] * x * 8 * z;
-					dX[14] = SH_C3[5] * z * 2 * x;              dY[14] = -SH_C3[5] * z * 2 * y;             dZ[14] = SH_C3[5] * (xx - yy);
-					dX[15] = SH_C3[6] * (3 * xx - 3 * yy);      dY[15] = -SH_C3[6] * x * 6 * y;
-					for (int k = 9; k <= 15; k++) b_st3(dsh, k, b_scl(l[k], dRGB));
-					float3 ax = b_scl(dX[9], b_ld3(sh, 9)), ay = b_scl(dY[9], b_ld3(sh, 9)), az = b_scl(dZ[10], b_ld3(sh, 10));
-					for (int k = 10; k <= 15; k++) { const float3 s = b_ld3(sh, k); ax = b_add(ax, b_scl(dX[k], s)); ay = b_add(ay, b_scl(dY[k], s)); }
-					for (int k = 11; k <= 14; k++) az = b_add(az, b_scl(dZ[k], b_ld3(sh, k)));
-					gx = b_add(gx, ax); gy = b_add(gy, ay); gz = b_add(gz, az);
-
-					for (int lev = 1; lev <= 2 && lev <= deg_t; lev++)
-					{
-						const int off = 16 * lev;
-						float tk, dtk_dt;
-						if (lev == 1)
-						{
-							tk = (float)cos(2 * REF_PI * dir_t / time_duration);
-							dtk_dt = (float)(sin(2 * REF_PI * dir_t / time_duration) * 2 * REF_PI / time_duration); // Q2
-						}
-						else
-						{
-							tk = (float)cos(2 * REF_PI * dir_t * 2 / time_duration);
-							dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / time_duration) * 2 * REF_PI * 2 / time_duration);
-						}
-						float3 st = make_float3(0, 0, 0), sx = st, sy = st, sz = st;
-						for (int k = 0; k < 16; k++)
-						{
-							const float3 s = b_ld3(sh, off + k);
-							b_st3(dsh, off + k, b_scl(tk * l[k], dRGB));
-							st = b_add(st, b_scl(l[k], s));
-							// terms the reference omits have a zero derivative entry (dX/dY/dZ == 0), e.g. dX[1], dX[2], dX[5]
-							sx = b_add(sx, b_scl(dX[k], s));
-							sy = b_add(sy, b_scl(dY[k], s));
-							sz = b_add(sz, b_scl(dZ[k], s));
-						}
-						gt = b_scl(dtk_dt, st); // Q3: overwrite, not accumulate
-						gx = b_add(gx, b_scl(tk, sx));
-						gy = b_add(gy, b_scl(tk, sy));
-						gz = b_add(gz, b_scl(tk, sz));
-					}
-				}
-			}
-		}
-		*dL_dt = b_dot(gt, dRGB);
-		return make_float3(b_dot(gx, dRGB), b_dot(gy, dRGB), b_dot(gz, dRGB));
-	}
-
 	__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const BwdArgs a)
 	{
 		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,22 +70,16 @@ namespace fdgs
 		float3 dscale = make_float3(0, 0, 0);
 		float dscale_t = 0.f;
 		float4 drot = make_float4(0, 0, 0, 0), drot_r = make_float4(0, 0, 0, 0);
-		const int n_sh_floats = a.shs ? a.M * 3 : 0;
-		float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * n_sh_floats : nullptr;
 		// unpack the accumulator record: colour 0-2, flow 3-4, mean2D 5-7, conic xx/xy/yy 8-10, opacity 11
 		const float4* rec = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS);
-		const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+		const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
 		const float3 g_color = make_float3(r0.x, r0.y, r0.z);
 		const float2 g_flow = make_float2(r0.w, r1.x);
 		const float3 g_mean2D = make_float3(r1.y, r1.z, r1.w);
 		const float3 g_conic = make_float3(r2.x, r2.y, r2.z);
 		float g_opacity = r2.w;
 
-		if (!visible)
-		{
-			for (int k = 0; k < n_sh_floats; k++) dsh[k] = 0.f;
-		}
-		else
+		if (visible)
 		{
 			const float3 mean = b_ld3(a.means, idx);
 			const float* cov3D = (a.cov3D_precomp ? a.cov3D_precomp : a.cov3D) + 6 * (size_t)idx;
@@ -317,36 +152,11 @@ namespace fdgs
 			}
 
 			// ---------------- SH (backward.cu:897-906) ----------------
+			// done by sh_bwd_kernel (sh_bwd.hip), which left its mean / time gradient in record words 12..15
 			if (a.shs)
 			{
-				const float3 campos = make_float3(a.campos[0], a.campos[1], a.campos[2]);
-				const float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z); // Q4
-				const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-				const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-				float3 dRGB = g_color;
-				const uint8_t cl = a.clamped[idx];
-				if (cl & 1) dRGB.x = 0.f;
-				if (cl & 2) dRGB.y = 0.f;
-				if (cl & 4) dRGB.z = 0.f;
-				const float* sh = a.shs + (size_t)idx * n_sh_floats;
-				float3 ddir;
-				int written;
-				if (a.gaussian_dim == 3 || a.force_sh_3d)
-				{
-					ddir = sh_bwd_3d(a.D, sh, dsh, dir, dRGB);
-					written = (a.D + 1) * (a.D + 1);
-				}
-				else
-				{
-					float dt_sh = 0.f;
-					ddir = sh_bwd_4d(a.D, a.D_t, sh, dsh, dir, dRGB, a.ts[idx] - a.timestamp, a.time_duration, &dt_sh);
-					dts += dt_sh;
-					written = (a.D + 1) * (a.D + 1);
-					if (a.D > 2) written = 16 * (1 + min(max(a.D_t, 0), 2));
-				}
-				for (int k = written * 3; k < n_sh_floats; k++) dsh[k] = 0.f; // coefficients above the active degree
-				const float3 dm = dnormvdv(dir_orig, ddir);
-				dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
+				dmean.x += r3.x; dmean.y += r3.y; dmean.z += r3.z;
+				dts += r3.w;
 			}
 
 			// ---------------- covariance (backward.cu:907-922) ----------------
@@ -534,7 +344,6 @@ namespace fdgs
 		a.gacc = out.grad_accum;
 		a.dL_dmean2D = out.dL_dmeans2D; a.dL_dcolor = out.dL_dcolors; a.dL_dflows = out.dL_dflows;
 		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
-		a.dL_dsh = s.shs ? out.dL_dsh : nullptr;
 		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;
 		a.dL_drot = out.dL_drotations; a.dL_drot_r = out.dL_drotations_r;
 		hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);

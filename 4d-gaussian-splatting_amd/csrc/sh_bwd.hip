@@ -1,0 +1,273 @@
+// sh_bwd.hip -- SH / 4D-SH backward with coalesced HBM traffic (gfx950).
+//
+// The reference evaluates this inside its per-Gaussian backward kernel (computeColorFromSH / _4D,
+// backward.cu:20-139, 144-481): every thread reads its own 12*M bytes of coefficients and writes its own
+// 12*M bytes of dL_dsh with a 12*M-byte stride between threads.  At M = 48 that is 576 B in and 576 B out per
+// Gaussian -- 80 % of all bytes the whole per-Gaussian backward moves -- so it gets its own kernel here:
+//   * a wave owns 64 consecutive Gaussians; their coefficient rows are staged block by block (16
+//     coefficients = 192 B per Gaussian) through a wave-private LDS tile with fully coalesced dwordx4 loads;
+//   * each lane then walks ITS Gaussian's row in LDS (row stride 49 floats: conflict free), accumulates the
+//     direction / time dot products in registers and overwrites the row with dL_dsh;
+//   * the tile is written back with coalesced dwordx4 stores (zeros for culled Gaussians, so dL_dsh never
+//     needs a memset).
+// The four numbers the geometry backward needs from here -- the mean gradient through the view direction
+// (3) and the time gradient (1) -- travel in the spare words 12..15 of the Gaussian's packed accumulator record.
+//
+// One table-driven formulation serves both the 3D and the 4D path: basis values l[k] and their x/y/z
+// derivatives for k < 16; blocks 1 and 2 reuse them times cos(2 pi j dt / T).  Bug-compatible with the
+// reference: Q1 dL_dsh[1] = l[0] * dRGB in the 4D path, Q2 sign of d cos/dt,
+// Q3 the last time block overwrites dRGB/dt, Q4 view direction from the SHIFTED mean.
+#pragma clang fp contract(off)
+#include "fdgs_common.h"
+#include "fdgs_math.h"
+
+namespace fdgs
+{
+	constexpr int SHB_STRIDE = 49;   // LDS row stride in floats (odd: lane-per-row access is conflict free)
+	constexpr int SHB_CH = 12;       // float4 chunks per Gaussian and block (16 coefficients x 3 / 4)
+
+	struct ShBwdArgs
+	{
+		int P, D, D_t, M;
+		const float *shs, *ts, *campos;
+		float timestamp, time_duration;
+		int gaussian_dim, force_sh_3d, vec_ok;
+		const int32_t* radii; const float* means; const uint8_t* clamped;
+		float* gacc; float* dL_dsh;
+	};
+
+	__device__ __forceinline__ float3 s_ld3(const float* p, int k) { return make_float3(p[3 * k], p[3 * k + 1], p[3 * k + 2]); }
+	__device__ __forceinline__ float3 s_add(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+	__device__ __forceinline__ float3 s_scl(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
+	__device__ __forceinline__ float s_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+	// basis values and derivatives (backward.cu:172-263); entries the reference has no term for stay zero
+	__device__ __forceinline__ void sh_tables(int deg, float x, float y, float z, bool promote, float* l, float* dX, float* dY, float* dZ)
+	{
+#pragma unroll
+		for (int k = 0; k < 16; k++) { l[k] = 0.f; dX[k] = 0.f; dY[k] = 0.f; dZ[k] = 0.f; }
+		l[0] = SH_C0;
+		if (deg > 0)
+		{
+			l[1] = -1 * SH_C1 * y; l[2] = SH_C1 * z; l[3] = -1 * SH_C1 * x;
+			dY[1] = -1 * SH_C1; dZ[2] = SH_C1; dX[3] = -1 * SH_C1;
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				l[4] = SH_C2[0] * xy; l[5] = SH_C2[1] * yz;
+				l[6] = promote ? (float)(SH_C2[2] * (2.0 * zz - xx - yy)) : SH_C2[2] * (2.f * zz - xx - yy);
+				l[7] = SH_C2[3] * xz; l[8] = SH_C2[4] * (xx - yy);
+				dX[4] = SH_C2[0] * y; dY[4] = SH_C2[0] * x;
+				dY[5] = SH_C2[1] * z; dZ[5] = SH_C2[1] * y;
+				dX[6] = -2 * SH_C2[2] * x; dY[6] = -2 * SH_C2[2] * y; dZ[6] = 4 * SH_C2[2] * z;
+				dX[7] = SH_C2[3] * z; dZ[7] = SH_C2[3] * x;
+				dX[8] = 2 * SH_C2[4] * x; dY[8] = -2 * SH_C2[4] * y;
+				if (deg > 2)
+				{
+					l[9] = SH_C3[0] * y * (3 * xx - yy);
+					l[10] = SH_C3[1] * xy * z;
+					l[11] = SH_C3[2] * y * (4 * zz - xx - yy);
+					l[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+					l[13] = SH_C3[4] * x * (4 * zz - xx - yy);
+					l[14] = SH_C3[5] * z * (xx - yy);
+					l[15] = SH_C3[6] * x * (xx - 3 * yy);
+					dX[9] = SH_C3[0] * y * 6 * x;               dY[9] = SH_C3[0] * (3 * xx - 3 * yy);
+					dX[10] = SH_C3[1] * yz;                     dY[10] = SH_C3[1] * xz;                     dZ[10] = SH_C3[1] * xy;
+					dX[11] = -SH_C3[2] * y * 2 * x;             dY[11] = SH_C3[2] * (4 * zz - xx - 3 * yy);  dZ[11] = SH_C3[2] * y * 8 * z;
+					dX[12] = -SH_C3[3] * z * 6 * x;             dY[12] = -SH_C3[3] * z * 6 * y;             dZ[12] = SH_C3[3] * (6 * zz - 3 * xx - 3 * yy);
+					dX[13] = SH_C3[4] * (4 * zz - 3 * xx - yy);  dY[13] = -SH_C3[4] * x * 2 * y;             dZ[13] = SH_C3[4] * x * 8 * z;
+					dX[14] = SH_C3[5] * z * 2 * x;              dY[14] = -SH_C3[5] * z * 2 * y;             dZ[14] = SH_C3[5] * (xx - yy);
+					dX[15] = SH_C3[6] * (3 * xx - 3 * yy);      dY[15] = -SH_C3[6] * x * 6 * y;
+				}
+			}
+		}
+	}
+
+	// ---- tile <-> global, coalesced ----
+	__device__ __forceinline__ void tile_load16(float* __restrict__ tile, const float* __restrict__ src, int g0, int P, size_t row_floats,
+	                                            int first_float, unsigned long long mask, int lane)
+	{
+		float4 v[SHB_CH];
+#pragma unroll
+		for (int i = 0; i < SHB_CH; i++)
+		{
+			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
+			const bool ok = g0 + g < P && ((mask >> g) & 1ull);
+			v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(g0 + g) * row_floats + first_float + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int i = 0; i < SHB_CH; i++)
+		{
+			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
+			float* d = tile + g * SHB_STRIDE + 4 * q;
+			d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+		}
+	}
+	__device__ __forceinline__ void tile_store16(const float* __restrict__ tile, float* __restrict__ dst, int g0, int P, size_t row_floats,
+	                                             int first_float, unsigned long long mask, int lane)
+	{
+#pragma unroll
+		for (int i = 0; i < SHB_CH; i++)
+		{
+			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
+			if (g0 + g < P)
+			{
+				const float* s = tile + g * SHB_STRIDE + 4 * q;
+				const bool live = (mask >> g) & 1ull;
+				const float4 v = live ? make_float4(s[0], s[1], s[2], s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+				*reinterpret_cast<float4*>(dst + (size_t)(g0 + g) * row_floats + first_float + 4 * q) = v;
+			}
+		}
+	}
+	// generic (any float count per row / alignment)
+	__device__ __forceinline__ void tile_load_any(float* __restrict__ tile, const float* __restrict__ src, int g0, int P, size_t row_floats,
+	                                              int first_float, int nf, unsigned long long mask, int lane)
+	{
+		int g = lane / nf, pos = lane - g * nf;
+		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
+		for (int e = lane; e < WAVE * nf; e += WAVE)
+		{
+			if (g0 + g < P && ((mask >> g) & 1ull)) tile[g * SHB_STRIDE + pos] = src[(size_t)(g0 + g) * row_floats + first_float + pos];
+			g += dg; pos += dpos;
+			if (pos >= nf) { pos -= nf; g++; }
+		}
+	}
+	__device__ __forceinline__ void tile_store_any(const float* __restrict__ tile, float* __restrict__ dst, int g0, int P, size_t row_floats,
+	                                               int first_float, int nf, unsigned long long mask, int lane)
+	{
+		int g = lane / nf, pos = lane - g * nf;
+		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
+		for (int e = lane; e < WAVE * nf; e += WAVE)
+		{
+			if (g0 + g < P) dst[(size_t)(g0 + g) * row_floats + first_float + pos] = ((mask >> g) & 1ull) ? tile[g * SHB_STRIDE + pos] : 0.f;
+			g += dg; pos += dpos;
+			if (pos >= nf) { pos -= nf; g++; }
+		}
+	}
+
+	__global__ void __launch_bounds__(256) sh_bwd_kernel(const ShBwdArgs a)
+	{
+		__shared__ float s_tile[256 / WAVE][WAVE * SHB_STRIDE];
+		const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+		float* tile = s_tile[wave];
+		float* row = tile + lane * SHB_STRIDE;
+		const int g0 = blockIdx.x * blockDim.x + wave * WAVE;
+		const int tid_g = g0 + lane;
+		const bool valid = tid_g < a.P;
+		const int idx = valid ? tid_g : a.P - 1;
+		const bool visible = valid && a.radii[idx] > 0; // backward.cu:873
+		const unsigned long long vmask = __ballot(visible);
+		const size_t row_floats = (size_t)3 * a.M;
+
+		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
+		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
+		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+
+		// per-Gaussian prologue
+		const float3 campos = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+		const float3 mean = make_float3(a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
+		const float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z); // Q4: shifted mean
+		const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+		const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+		float3 dRGB = make_float3(a.gacc[(size_t)idx * GRAD_ACC_WORDS + 0], a.gacc[(size_t)idx * GRAD_ACC_WORDS + 1], a.gacc[(size_t)idx * GRAD_ACC_WORDS + 2]);
+		const uint8_t cl = a.clamped[idx];
+		if (cl & 1) dRGB.x = 0.f;   // clamped channels get no gradient (backward.cu:158-161)
+		if (cl & 2) dRGB.y = 0.f;
+		if (cl & 4) dRGB.z = 0.f;
+		const float dir_t = sh3d ? 0.f : a.ts[idx] - a.timestamp;
+		float l[16], dX[16], dY[16], dZ[16];
+		sh_tables(a.D, dir.x, dir.y, dir.z, !sh3d, l, dX, dY, dZ);
+
+		float3 gx = make_float3(0.f, 0.f, 0.f), gy = gx, gz = gx, gt = gx;
+		for (int blk = 0; blk < nblocks; blk++)
+		{
+			const int nk = (blk == 0) ? ncoef0 : 16;
+			const int first_float = 48 * blk;
+			const bool vec = a.vec_ok && nk == 16;
+			if (vec) tile_load16(tile, a.shs, g0, a.P, row_floats, first_float, vmask, lane);
+			else tile_load_any(tile, a.shs, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane);
+			__syncthreads();
+			if (visible)
+			{
+				float tk = 1.f, dtk_dt = 0.f;
+				if (blk == 1)
+				{
+					tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
+					dtk_dt = (float)(sin(2 * REF_PI * dir_t / a.time_duration) * 2 * REF_PI / a.time_duration); // Q2
+				}
+				else if (blk == 2)
+				{
+					tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+					dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
+				}
+				float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
+#pragma unroll
+				for (int k = 0; k < 16; k++)   // fully unrolled: the tables stay in registers (no dynamic indexing)
+				{
+					if (k >= nk) break;
+					const float3 s = s_ld3(row, k);
+					float basis = l[k];
+					if (blk == 0 && k == 1 && !sh3d) basis = l[0]; // Q1
+					const float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
+					row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
+					st = s_add(st, s_scl(l[k], s));
+					sx = s_add(sx, s_scl(dX[k], s));
+					sy = s_add(sy, s_scl(dY[k], s));
+					sz = s_add(sz, s_scl(dZ[k], s));
+				}
+				if (blk == 0) { gx = sx; gy = sy; gz = sz; }
+				else
+				{
+					gx = s_add(gx, s_scl(tk, sx)); gy = s_add(gy, s_scl(tk, sy)); gz = s_add(gz, s_scl(tk, sz));
+					gt = s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
+				}
+			}
+			__syncthreads();
+			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane);
+			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane);
+			__syncthreads();
+		}
+		// coefficients above the active degree get a zero gradient
+		{
+			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
+			const int rest = (int)row_floats - written;
+			if (rest > 0) tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written, rest > 48 ? 48 : rest, 0ull, lane);
+			for (int done = 48; done < rest; done += 48)
+				tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written + done, min(48, rest - done), 0ull, lane);
+		}
+		if (valid)
+		{
+			float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (visible)
+			{
+				const float3 ddir = make_float3(s_dot(gx, dRGB), s_dot(gy, dRGB), s_dot(gz, dRGB));
+				// dnormvdv, auxiliary.h:108-118
+				const float3 v = dir_orig;
+				const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+				const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+				o.x = ((+sum2 - v.x * v.x) * ddir.x - v.y * v.x * ddir.y - v.z * v.x * ddir.z) * invsum32;
+				o.y = (-v.x * v.y * ddir.x + (sum2 - v.y * v.y) * ddir.y - v.z * v.y * ddir.z) * invsum32;
+				o.z = (-v.x * v.z * ddir.x - v.y * v.z * ddir.y + (sum2 - v.z * v.z) * ddir.z) * invsum32;
+				o.w = sh3d ? 0.f : s_dot(gt, dRGB);
+			}
+			reinterpret_cast<float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS)[3] = o;
+		}
+	}
+
+	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out, const char* geom, hipStream_t stream)
+	{
+		if (s.shs == nullptr || s.M <= 0) return hipSuccess;
+		const GeomLayout L = geom_layout(s.P);
+		ShBwdArgs a;
+		a.P = s.P; a.D = s.D; a.D_t = s.D_t; a.M = s.M;
+		a.shs = s.shs; a.ts = s.ts; a.campos = s.campos;
+		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
+		a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+		a.vec_ok = ((reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out.dL_dsh) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
+		a.radii = in.radii; a.means = in.out_means3D;
+		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
+		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh;
+		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		return hipGetLastError();
+	}
+}

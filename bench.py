@@ -40,7 +40,9 @@ ALGO_BYTES = {
     "preprocess_fwd": lambda P, Pv, M, R, N, T: 68 * P + (12 * M + 87) * Pv,
     "blend_fwd": lambda P, Pv, M, R, N, T: 52 * R + 32 * N,
     "blend_bwd": lambda P, Pv, M, R, N, T: 96 * R + 36 * N,
-    "preprocess_bwd": lambda P, Pv, M, R, N, T: (68 + 24 * M + 150 + 104) * Pv,  # incl. the fused cov2D backward
+    # BASELINE.md's preprocess-bwd figure (68 + 24 M + 150) P_v + cov2D-bwd 104 P_v, split over our two kernels:
+    "sh_bwd": lambda P, Pv, M, R, N, T: (24 * M + 44) * Pv,
+    "preprocess_bwd": lambda P, Pv, M, R, N, T: (68 + 150 + 104 + 64 - 44) * Pv,  # incl. the fused cov2D backward + record read
     # our two-level sort: 4 passes over P pairs + 2 passes over R pairs (reads keys for the histogram, then pairs)
     "depth_sort": lambda P, Pv, M, R, N, T: 4 * (4 + 8 + 8) * P,
     "tile_sort": lambda P, Pv, M, R, N, T: 2 * (4 + 8 + 8) * R,

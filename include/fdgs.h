@@ -206,7 +206,8 @@ int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
 #define FDGS_STAGE_BLEND_BWD 7
 #define FDGS_STAGE_PREPROCESS_BWD 8
 #define FDGS_STAGE_GRAD_ZERO 9
-#define FDGS_NUM_STAGES 10
+#define FDGS_STAGE_SH_BWD 10
+#define FDGS_NUM_STAGES 11
 int fdgs_profile_enable(int on);
 int fdgs_profile_read(int stage, double* total_ms, int64_t* samples);
 int fdgs_profile_reset(void);
