@@ -14,8 +14,10 @@ namespace fdgs
 	constexpr int TILE_Y = 16;
 	constexpr int WAVE = 64;            // gfx950 wavefront
 	constexpr int SORT_THREADS = 256;   // radix sort workgroup
-	constexpr int SORT_ITEMS = 16;      // keys per thread
-	constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
+	constexpr int SORT_ITEMS = 16;      // keys per thread (large inputs: 4096 keys per workgroup)
+	constexpr int SORT_ITEMS_SMALL = 4; // keys per thread for inputs <= 1 M keys (1024 per workgroup: fills the chip)
+	static inline int sort_items_for(int n) { return n <= (1 << 20) ? SORT_ITEMS_SMALL : SORT_ITEMS; }
+	static inline int sort_blocks(int n) { return (n + SORT_THREADS * sort_items_for(n) - 1) / (SORT_THREADS * sort_items_for(n)); }
 	constexpr int RADIX_BITS = 8;
 	constexpr int RADIX = 1 << RADIX_BITS;
 	constexpr int SCAN_CHUNK = 4096;
@@ -52,7 +54,7 @@ namespace fdgs
 		for (int i = 0; i < 2; i++) { L.sort_val[i] = o; o = align_up(o + p * 4); }
 		L.offsets = o; o = align_up(o + p * 4);
 		L.scan_block = o; o = align_up(o + ((size_t)div_up((int)p, SCAN_CHUNK) + 2) * 4);
-		L.hist = o; o = align_up(o + (size_t)RADIX * (div_up((int)p, SORT_CHUNK) + 1) * 4);
+		L.hist = o; o = align_up(o + (size_t)RADIX * (sort_blocks((int)p) + 1) * 4);
 		L.total = o;
 		return L;
 	}
@@ -85,7 +87,7 @@ namespace fdgs
 		const size_t r = (size_t)(R > 0 ? R : 1);
 		for (int i = 0; i < 2; i++) { L.key[i] = o; o = align_up(o + r * 4); }
 		for (int i = 0; i < 2; i++) { L.val[i] = o; o = align_up(o + r * 4); }
-		L.hist = o; o = align_up(o + (size_t)RADIX * (div_up((int)r, SORT_CHUNK) + 1) * 4);
+		L.hist = o; o = align_up(o + (size_t)RADIX * (sort_blocks((int)r) + 1) * 4);
 		L.total = o;
 		return L;
 	}
