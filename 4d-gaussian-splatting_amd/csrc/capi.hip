@@ -36,7 +36,7 @@ static int fail(int code, const char* fmt, ...)
 // ---- optional per-stage HIP-event timing (fdgs_profile_*) ----
 namespace
 {
-	constexpr int PROF_CAP = 256;
+	constexpr int PROF_CAP = 2048; // pending event pairs per stage before a (blocking) flush
 	struct StageProf
 	{
 		hipEvent_t start[PROF_CAP], stop[PROF_CAP];

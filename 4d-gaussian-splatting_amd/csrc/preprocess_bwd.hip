@@ -32,7 +32,7 @@ namespace fdgs
 		const float *shs, *opacities, *ts, *scales, *scales_t, *rotations, *rotations_r, *cov3D_precomp;
 		const float *viewmatrix, *projmatrix, *campos;
 		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
-		int rot_4d, gaussian_dim, force_sh_3d, raw;
+		int rot_4d, gaussian_dim, force_sh_3d, raw, accum;
 		const int32_t* radii; const float* means; /* out_means3D */
 		const float* cov3D; const uint8_t* clamped;
 		const float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
@@ -312,10 +312,23 @@ namespace fdgs
 		b_st3(a.dL_dmean2D, idx, g_mean2D);
 		b_st3(a.dL_dcolor, idx, g_color);
 		a.dL_dflows[2 * (size_t)idx] = g_flow.x; a.dL_dflows[2 * (size_t)idx + 1] = g_flow.y;
-		a.dL_dopacity[idx] = g_opacity;
-		b_st3(a.dL_dmeans, idx, dmean);
 #pragma unroll
 		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+		if (a.accum)
+		{
+			// gradient accumulation over the views of one optimizer step: add into the parameter gradients
+			if (!visible) return; // nothing to add
+			a.dL_dopacity[idx] += g_opacity;
+			a.dL_dmeans[3 * (size_t)idx] += dmean.x; a.dL_dmeans[3 * (size_t)idx + 1] += dmean.y; a.dL_dmeans[3 * (size_t)idx + 2] += dmean.z;
+			if (a.dL_dts) a.dL_dts[idx] += dts;
+			if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] += dscale.x; a.dL_dscale[3 * (size_t)idx + 1] += dscale.y; a.dL_dscale[3 * (size_t)idx + 2] += dscale.z; }
+			if (a.dL_dscale_t) a.dL_dscale_t[idx] += dscale_t;
+			if (a.dL_drot) { float4* d = reinterpret_cast<float4*>(a.dL_drot) + idx; const float4 o = *d; *d = make_float4(o.x + drot.x, o.y + drot.y, o.z + drot.z, o.w + drot.w); }
+			if (a.dL_drot_r) { float4* d = reinterpret_cast<float4*>(a.dL_drot_r) + idx; const float4 o = *d; *d = make_float4(o.x + drot_r.x, o.y + drot_r.y, o.z + drot_r.z, o.w + drot_r.w); }
+			return;
+		}
+		a.dL_dopacity[idx] = g_opacity;
+		b_st3(a.dL_dmeans, idx, dmean);
 		if (a.dL_dts) a.dL_dts[idx] = dts;
 		if (a.dL_dscale) b_st3(a.dL_dscale, idx, dscale);
 		if (a.dL_dscale_t) a.dL_dscale_t[idx] = dscale_t;
@@ -337,7 +350,7 @@ namespace fdgs
 		a.focal_y = s.H / (2.0f * s.tan_fovy); // rasterizer_impl.cu:424-425
 		a.focal_x = s.W / (2.0f * s.tan_fovx);
 		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
-		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.raw = s.raw_params;
+		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.raw = s.raw_params; a.accum = out.accumulate;
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.cov3D = reinterpret_cast<const float*>(geom + L.cov3D);
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);

@@ -31,7 +31,7 @@ namespace fdgs
 		int P, D, D_t, M;
 		const float *shs, *ts, *campos;
 		float timestamp, time_duration;
-		int gaussian_dim, force_sh_3d, vec_ok;
+		int gaussian_dim, force_sh_3d, vec_ok, accum;
 		const int32_t* radii; const float* means; const uint8_t* clamped;
 		float* gacc; float* dL_dsh;
 	};
@@ -104,7 +104,7 @@ namespace fdgs
 		}
 	}
 	__device__ __forceinline__ void tile_store16(const float* __restrict__ tile, float* __restrict__ dst, int g0, int P, size_t row_floats,
-	                                             int first_float, unsigned long long mask, int lane)
+	                                             int first_float, unsigned long long mask, int lane, bool accum)
 	{
 #pragma unroll
 		for (int i = 0; i < SHB_CH; i++)
@@ -114,8 +114,15 @@ namespace fdgs
 			{
 				const float* s = tile + g * SHB_STRIDE + 4 * q;
 				const bool live = (mask >> g) & 1ull;
-				const float4 v = live ? make_float4(s[0], s[1], s[2], s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-				*reinterpret_cast<float4*>(dst + (size_t)(g0 + g) * row_floats + first_float + 4 * q) = v;
+				float4* d = reinterpret_cast<float4*>(dst + (size_t)(g0 + g) * row_floats + first_float + 4 * q);
+				float4 v = live ? make_float4(s[0], s[1], s[2], s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+				if (accum)
+				{
+					if (!live) continue; // adding zero
+					const float4 o = *d;
+					v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+				}
+				*d = v;
 			}
 		}
 	}
@@ -133,13 +140,19 @@ namespace fdgs
 		}
 	}
 	__device__ __forceinline__ void tile_store_any(const float* __restrict__ tile, float* __restrict__ dst, int g0, int P, size_t row_floats,
-	                                               int first_float, int nf, unsigned long long mask, int lane)
+	                                               int first_float, int nf, unsigned long long mask, int lane, bool accum)
 	{
 		int g = lane / nf, pos = lane - g * nf;
 		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
 		for (int e = lane; e < WAVE * nf; e += WAVE)
 		{
-			if (g0 + g < P) dst[(size_t)(g0 + g) * row_floats + first_float + pos] = ((mask >> g) & 1ull) ? tile[g * SHB_STRIDE + pos] : 0.f;
+			if (g0 + g < P)
+			{
+				float* d = dst + (size_t)(g0 + g) * row_floats + first_float + pos;
+				const bool live = (mask >> g) & 1ull;
+				if (!accum) *d = live ? tile[g * SHB_STRIDE + pos] : 0.f;
+				else if (live) *d += tile[g * SHB_STRIDE + pos];
+			}
 			g += dg; pos += dpos;
 			if (pos >= nf) { pos -= nf; g++; }
 		}
@@ -223,17 +236,18 @@ namespace fdgs
 				}
 			}
 			__syncthreads();
-			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane);
-			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane);
+			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
+			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
 			__syncthreads();
 		}
-		// coefficients above the active degree get a zero gradient
+		// coefficients above the active degree get a zero gradient (nothing to add when accumulating)
+		if (!a.accum)
 		{
 			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
 			const int rest = (int)row_floats - written;
-			if (rest > 0) tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written, rest > 48 ? 48 : rest, 0ull, lane);
+			if (rest > 0) tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written, rest > 48 ? 48 : rest, 0ull, lane, false);
 			for (int done = 48; done < rest; done += 48)
-				tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written + done, min(48, rest - done), 0ull, lane);
+				tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written + done, min(48, rest - done), 0ull, lane, false);
 		}
 		if (valid)
 		{
@@ -266,7 +280,7 @@ namespace fdgs
 		a.vec_ok = ((reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out.dL_dsh) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
-		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh;
+		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
 		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();
 	}

@@ -8,8 +8,9 @@ _rotation_r`` and ``get_features``) to the same kernels with ``fdgs_scene.raw_pa
 scene/gaussian_model.py:179-219 are applied inside preprocess and their derivatives inside preprocess-backward.
 With ``grad_sink`` (e.g. ``GaussianParams.grad_sink()``) the backward writes each gradient straight into the
 caller's buffers -- the slices of the flat data-parallel bucket -- and returns no gradient to autograd for those
-inputs, so there is no accumulation pass and no zero_grad.  (A sink is OVERWRITTEN by every backward: use it with
-one view per optimizer step and rank, which is the frame-parallel scheme; otherwise omit it.)
+inputs, so there is no accumulation pass and no zero_grad.  A sink is OVERWRITTEN by a backward with
+``accumulate=False`` (the first view of an optimizer step) and ADDED to with ``accumulate=True`` (the following
+views of the same step: the reference sums ``loss / batch_size`` over ``batch_size`` views, train.py:104-166).
 
 Covers the default pipeline (in-kernel covariance and SH, rot_4d or not, no env map); everything else goes
 through ``render()``.  Same result dict as ``render()``.
@@ -24,7 +25,7 @@ from .gaussian_renderer.diff_gaussian_rasterization import GaussianRasterization
 class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
-                prefilter_var, raster_settings, grad_sink):
+                prefilter_var, raster_settings, grad_sink, accumulate):
         rs = raster_settings
         e = torch.Tensor([])
         args = (rs.bg, means3D, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
@@ -32,7 +33,7 @@ class _RasterizeRaw(torch.autograd.Function):
                 rs.image_height, rs.image_width, sh, rs.sh_degree, rs.sh_degree_t, rs.campos, rs.timestamp,
                 rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, rs.prefiltered, rs.debug)
         (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = _C.rasterize_gaussians(*args, raw_params=True)
-        ctx.rs, ctx.R, ctx.prefilter_var, ctx.sink = rs, R, prefilter_var, grad_sink
+        ctx.rs, ctx.R, ctx.prefilter_var, ctx.sink, ctx.accumulate = rs, R, prefilter_var, grad_sink, bool(accumulate)
         ctx.save_for_backward(means3D, out_means3D, scaling_raw, rotation_raw, radii, sh, opacity_raw, ts, scaling_t_raw,
                               rotation_r_raw, geom, binb, img)
         ctx.mark_non_differentiable(radii)
@@ -52,7 +53,7 @@ class _RasterizeRaw(torch.autograd.Function):
                 rs.debug)
         sink = ctx.sink
         (d_means2D, _d_colors, d_opacity, d_means3D, _d_cov3D, d_sh, _d_flows, d_ts, d_scales, d_scales_t, d_rot,
-         d_rot_r) = _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink)
+         d_rot_r) = _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=ctx.accumulate)
 
         def ret(name, given, g):
             if not _is_given(given):
@@ -65,10 +66,10 @@ class _RasterizeRaw(torch.autograd.Function):
                 ret("dL_dopacity", opacity_raw, d_opacity), ret("dL_dts", ts, d_ts),
                 ret("dL_dscales", scaling_raw, d_scales), ret("dL_dscales_t", scaling_t_raw, d_scales_t),
                 ret("dL_drotations", rotation_raw, d_rot), ret("dL_drotations_r", rotation_r_raw, d_rot_r),
-                None, None, None)
+                None, None, None, None)
 
 
-def render_raw(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, grad_sink=None):
+def render_raw(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, grad_sink=None, accumulate=False):
     """``render()`` with the activations fused into the kernels; see the module docstring."""
     if pipe.compute_cov3D_python or pipe.convert_SHs_python or pipe.env_map_res:
         raise ValueError("render_raw covers the default pipeline only; use render() for the Python covariance / SH / env-map branches")
@@ -91,6 +92,6 @@ def render_raw(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modif
     prefilter_var = pc.prefilter_var if (is_4d and pc.prefilter_var > 0.0) else -1.0
     color, radii, depth, alpha, flow = _RasterizeRaw.apply(
         xyz, screenspace_points, pc.get_features, pc._opacity, ts, pc._scaling, scaling_t, pc._rotation, rotation_r,
-        prefilter_var, rs, grad_sink)
+        prefilter_var, rs, grad_sink, accumulate)
     return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth": depth, "alpha": alpha, "flow": flow}

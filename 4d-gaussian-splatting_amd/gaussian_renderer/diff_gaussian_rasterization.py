@@ -126,11 +126,12 @@ class _NativeRasterizer:
                                      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
-                                     imageBuffer, debug, *, raw_params=False, grad_out=None):
+                                     imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
-        preallocated contiguous tensors the kernels write into (e.g. views of a flat gradient bucket)."""
+        preallocated contiguous tensors the kernels write into (e.g. views of a flat gradient bucket);
+        ``accumulate``: the kernels ADD into those parameter gradients instead of overwriting them."""
         dev = means3D.device
         H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])  # rasterize_points.cu:192-193
         scene, keep = self._scene(bg, means3D, colors, flows_2d, opacities, ts, scales, scales_t, rotations,
@@ -163,9 +164,12 @@ class _NativeRasterizer:
         bin_ = _capi.FdgsBackwardIn(gin[0].data_ptr(), gin[1].data_ptr(), gin[2].data_ptr(), gin[3].data_ptr(),
                                     _capi._ptr(radii_c), _capi._ptr(om_c), _capi._ptr(geomBuffer),
                                     _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R))
-        bout = _capi.FdgsBackwardOut(*[_capi._ptr(g[k]) for k in (
+        if accumulate and not grad_out:
+            raise RuntimeError("fdgs: accumulate=True needs grad_out buffers that already hold gradients")
+        ptrs = [_capi._ptr(g[k]) for k in (
             "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
-            "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r", "grad_accum")])
+            "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r")]
+        bout = _capi.FdgsBackwardOut(*ptrs, int(bool(accumulate)), _capi._ptr(g["grad_accum"]))
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
                                                    _capi.current_stream_handle(dev))

@@ -147,6 +147,11 @@ typedef struct fdgs_backward_out
 	float* dL_dscales_t;    /* [P]                                                 */
 	float* dL_drotations;   /* [P,4]                                               */
 	float* dL_drotations_r; /* [P,4]                                               */
+	int32_t accumulate;     /* 0: the parameter gradients (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales,
+	                           dL_dscales_t, dL_drotations, dL_drotations_r) are overwritten; 1: the kernels ADD into
+	                           them (gradient accumulation over the views of one optimizer step, reference
+	                           train.py:104-166).  The per-view outputs (dL_dmeans2D, dL_dcolors, dL_dflows,
+	                           dL_dcov3D) are always overwritten. */
 	float* grad_accum;      /* [P,16] scratch: packed per-Gaussian accumulators of the blend backward
 	                           (colour 3, flow 2, mean2D 3, conic xx/xy/yy 3 (Q12 convention), opacity 1, pad 4) */
 } fdgs_backward_out;

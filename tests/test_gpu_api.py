@@ -184,3 +184,32 @@ def test_c5_stress_size_properties(gpu_device):
     np.testing.assert_array_equal(a["tiles_touched"][:20000], ref["tiles_touched"])
     vis = ref["radii"] > 0
     np.testing.assert_array_equal(a["depths"][:20000][vis].view(np.uint32), ref["depths"][vis].view(np.uint32))
+
+
+def test_gradient_accumulation_over_views(gpu_device):
+    """accumulate=True (fdgs_backward_out.accumulate): two views accumulated into the sink equal the sum of the two
+    views' separately computed gradients (the reference sums loss / batch_size over the batch, train.py:104-166)."""
+    from fdgs import train_host
+    from fdgs.fused import render_raw
+    cfg = synth.SceneConfig("acc", 5000, 176, 144, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=8)
+    bg = torch.zeros(3, device=gpu_device)
+    pipe = train_host.PipelineFlags()
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=t) for t in (3.0, 7.0)]
+    w = synth.make_upstream_grads(scene["W"], scene["H"], seed=5, scale=1e-2)["grad_color"].to(gpu_device)
+
+    singles = []
+    for cam in cams:
+        m = train_host.GaussianParams(scene, gpu_device)
+        (render_raw(cam, m, pipe, bg, grad_sink=m.grad_sink())["render"] * w).sum().backward()
+        singles.append(m.flat_grad.clone())
+    m = train_host.GaussianParams(scene, gpu_device)
+    m.flat_grad.fill_(float("nan"))
+    sink = m.grad_sink()
+    for v, cam in enumerate(cams):
+        (render_raw(cam, m, pipe, bg, grad_sink=sink, accumulate=v > 0)["render"] * w).sum().backward()
+    want = singles[0] + singles[1]
+    assert torch.isfinite(m.flat_grad).all()
+    err = (m.flat_grad - want).abs()
+    scale = max(1.0, want.abs().max().item())
+    assert (err > 1e-4 * scale).float().mean().item() <= 1e-4 and err.max().item() <= 1e-2 * scale, err.max().item()
