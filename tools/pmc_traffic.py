@@ -24,7 +24,7 @@ STAGE_OF = {
     "radix_hist_kernel": "radix_sort", "radix_scan_kernel": "radix_sort", "radix_scatter_kernel": "radix_sort",
     "emit_instances_kernel": "emit_instances", "tile_ranges_kernel": "tile_ranges",
     "offsets_reduce_kernel": "offset_scan", "offsets_scan_sums_kernel": "offset_scan", "offsets_final_kernel": "offset_scan",
-    "ssim_fwd_kernel": "ssim_fwd", "ssim_bwd_kernel": "ssim_bwd",
+    "ssim_fwd_kernel": "ssim_fwd", "ssim_bwd_kernel": "ssim_bwd", "sh_bwd_kernel": "sh_bwd", "adam_kernel": "adam",
 }
 
 
