@@ -124,9 +124,8 @@ namespace fdgs
 
 		// The slot this lane owns after transpose_reduce16 (12 live slots in lanes 0..15) is word `slot` of the
 		// Gaussian's packed 64-byte accumulator record: colour 0-2, flow 3-4, mean2D 5-7, conic xx/xy/yy 8-10,
-		// opacity 11.  One record = one cache line, so the 12-lane atomic instruction is ONE memory-side
-		// request instead of five (device-scope float atomics are RMWs at the memory side on this chip and
-		// their request rate, not the VALU, bounds this kernel).
+		// opacity 11.  One record = one 64-B segment, so the 12-lane atomic instruction is ONE memory-side
+		// request instead of five (the reference scatters into five arrays, backward.cu:1116-1133).
 		const int slot = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 		float* const slot_ptr = gacc + slot;
 		const bool slot_writer = lane < 16 && slot < NG;
