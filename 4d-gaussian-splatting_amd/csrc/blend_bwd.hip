@@ -12,67 +12,126 @@
 // contributing (pixel, Gaussian) pair (backward.cu:1076-1134):
 //   * list entries are culled against the wave's 8x8 block and compacted
 //     (blend_common.h), and the wave starts at ITS deepest last contributor;
+//   * the kernel is VALU-issue bound (tools/probe/README.md), so the per-entry body is written for
+//     instruction count: branch-free after one wave-uniform skip, the seven per-channel recurrences
+//     collapsed into one scalar recurrence, packed-fp32 (v_pk_*) arithmetic on natural pairs;
 //   * the 12 per-lane values are summed over the 64 pixels with a butterfly
 //     "transpose-reduce" on DPP lane permutes: at every halving step a lane keeps one
 //     half of its slots and hands the other half to its partner, so after 4 steps
-//     each lane of a 16-lane row owns ONE fully row-reduced slot (24+12+12+3 VALU ops
-//     instead of 12 x 6), two cross-row shuffles finish the sum, and lanes 0..15 then
-//     issue ONE global_atomic_add_f32 instruction for the 12 live slots, all inside the Gaussian's
-//     packed 64-byte accumulator record (one cache line = one memory-side atomic request);
+//     each lane of a 16-lane row owns ONE fully row-reduced slot (29 VALU ops
+//     instead of 12 x 6), two cross-row shuffles finish the sum, and lanes 0..11 then
+//     issue ONE global_atomic_add_f32 instruction for 12 consecutive words of the Gaussian's
+//     packed 64-byte accumulator record (one memory-side atomic request);
 //   => one atomic request per surviving (block, Gaussian) instead of 12 per (pixel, Gaussian).
 //   preprocess_bwd unpacks the records into the user-visible gradient tensors.
 #include "blend_common.h"
 
 namespace fdgs
 {
-	constexpr int NG = 12; // gradient words per Gaussian: colour 3, flow 2, mean2D 3, conic 3, opacity 1
+	constexpr int NG = 12; // gradient words per Gaussian: colour 3, depth 1, flow 2, mean2D 2, conic 3, opacity 1
 
-	template <int CTRL>
-	__device__ __forceinline__ float dpp_mov(float v)
+	// The same butterfly, hand-scheduled, with the partner order reversed (lane^8, ^4, ^2, ^1) so that the two
+	// widest steps can use DPP bank masks (a bank = 4 consecutive lanes of a row, i.e. lane bits 2-3): the
+	// lanes of one class are written by one v_add_f32_dpp and the other class by a second one -- no
+	// v_cndmask selects -- and every step works in place.  Slots 12..15 carry junk (nobody reads them).
+	// 29 VALU instead of 51; the explicit s_nops cover the VALU-write -> DPP-read hazard (2 wait states)
+	// that the compiler cannot see inside inline asm.
+	// On return lane L of every 16-lane row holds its ROW's sum of slot (L & 15).
+	__device__ __forceinline__ float row_transpose_reduce12(float (&g)[12])
 	{
-		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+		const unsigned long long m1 = 0xCCCCCCCCCCCCCCCCull, m0 = 0xAAAAAAAAAAAAAAAAull;
+		asm volatile(
+			"s_nop 1\n\t"
+			// step 1: partner = lane ^ 8; lanes 0-7 of a row keep slots i, lanes 8-15 keep slots i + 8
+			"v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			// step 2: partner = lane ^ 4; banks 0,2 (bit 2 clear) read lane+4 and keep slots i, banks 1,3 read lane-4, keep i + 4
+			"v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			// step 3: partner = lane ^ 2
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %2, %12\n\t"
+			"v_cndmask_b32_e64 %1, %1, %3, %12\n\t"
+			"s_nop 1\n\t"
+			// step 4: partner = lane ^ 1
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %1, %13\n\t"
+			: "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7])
+			: "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "s"(m1), "s"(m0));
+		return g[0];
 	}
 
-	// Sums 16 slots (v[12..15] are zero) over the wave.  On return lane L (any row) holds the total of
-	// slot  s(L) = 8*b0 + 4*b1 + 2*b2 + b3  (b_i = bit i of L & 15).
-	__device__ __forceinline__ float transpose_reduce16(const float (&v)[16], int lane)
+	// The same reduction when only the colour image has an upstream gradient (AUX = false below): slots 3-5
+	// (depth, flow) are identically zero, so their instructions are dropped (24 VALU); lanes 3-5 end up with
+	// junk that nobody writes.  g[3..5] are not read.
+	__device__ __forceinline__ float row_transpose_reduce9(float (&g)[12])
 	{
-		const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-		float w[8], u[4], t[2];
-#pragma unroll
-		for (int i = 0; i < 8; i++)   // partner = lane ^ 1  (quad_perm [1,0,3,2])
-		{
-			const float keep = b0 ? v[i + 8] : v[i];
-			const float send = b0 ? v[i] : v[i + 8];
-			w[i] = keep + dpp_mov<0xB1>(send);
-		}
-#pragma unroll
-		for (int i = 0; i < 4; i++)   // partner = lane ^ 2  (quad_perm [2,3,0,1])
-		{
-			const float keep = b1 ? w[i + 4] : w[i];
-			const float send = b1 ? w[i] : w[i + 4];
-			u[i] = keep + dpp_mov<0x4E>(send);
-		}
-#pragma unroll
-		for (int i = 0; i < 2; i++)   // partner = lane ^ 4  (row_shr:4 for bit2 lanes, row_shl:4 otherwise)
-		{
-			const float keep = b2 ? u[i + 2] : u[i];
-			const float send = b2 ? u[i] : u[i + 2];
-			const float from_lo = dpp_mov<0x114>(send); // row_shr:4: lane i <- lane i-4
-			const float from_hi = dpp_mov<0x104>(send); // row_shl:4: lane i <- lane i+4
-			t[i] = keep + (b2 ? from_lo : from_hi);
-		}
-		float r;
-		{                             // partner = lane ^ 8  (row_ror:8)
-			const float keep = b3 ? t[1] : t[0];
-			const float send = b3 ? t[0] : t[1];
-			r = keep + dpp_mov<0x128>(send);
-		}
-		r += __shfl_xor(r, 16);       // across the four 16-lane rows
-		r += __shfl_xor(r, 32);
-		return r;
+		const unsigned long long m1 = 0xCCCCCCCCCCCCCCCCull, m0 = 0xAAAAAAAAAAAAAAAAull;
+		float w3;
+		asm volatile(
+			"s_nop 1\n\t"
+			"v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %2, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %3, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %2, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %3, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %2, %10\n\t"
+			"v_cndmask_b32_e64 %1, %1, %3, %10\n\t"
+			"s_nop 1\n\t"
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %1, %11\n\t"
+			: "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "=&v"(w3), "+v"(g[6]), "+v"(g[7])
+			: "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "s"(m1), "s"(m0));
+		return g[0];
 	}
 
+	template <bool AUX>
+	__device__ __forceinline__ void reduce_and_add(float (&g)[12], float* slot_ptr, bool slot_writer, uint32_t eid)
+	{
+		float total = AUX ? row_transpose_reduce12(g) : row_transpose_reduce9(g);
+		total += __shfl_xor(total, 16);       // across the four 16-lane rows
+		total += __shfl_xor(total, 32);
+		if (slot_writer) atomicAdd(slot_ptr + (size_t)eid * GRAD_ACC_WORDS, total);
+	}
+
+	// AUX = false: only the colour image carries an upstream gradient (dL_dout_depth / _alpha / _flow are NULL = zero),
+	// the usual case in training (photometric loss on the render only): the depth / flow / mask terms drop out.
+	template <bool AUX>
 	__global__ void __launch_bounds__(WAVE) blend_bwd_kernel(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
 		int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
@@ -81,12 +140,12 @@ namespace fdgs
 		const float* __restrict__ dL_dpix_flow,
 		float* __restrict__ gacc)
 	{
-		// wave-private queue of the surviving entries of the current chunk (+1: inert padding entry for the prefetch)
-		__shared__ float4 s_a[WAVE + 1];
-		__shared__ float4 s_b[WAVE + 1];
-		__shared__ float4 s_c[WAVE + 1];
-		__shared__ uint32_t s_pos[WAVE + 1];
-		__shared__ uint32_t s_id[WAVE + 1];
+		// wave-private queue of the surviving entries of the current chunk (+2: inert padding entries for the prefetch)
+		__shared__ float4 s_a[WAVE + 2];
+		__shared__ float4 s_b[WAVE + 2];
+		__shared__ float4 s_c[WAVE + 2];
+		__shared__ uint32_t s_pos[WAVE + 2];
+		__shared__ uint32_t s_id[WAVE + 2];
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -114,24 +173,80 @@ namespace fdgs
 		float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLf0 = 0.f, dLf1 = 0.f, dL_depth = 0.f, dL_mask = 0.f;
 		if (inside)
 		{
-			dLp0 = dL_dpixels[0 * HW + pix_id]; dLp1 = dL_dpixels[1 * HW + pix_id]; dLp2 = dL_dpixels[2 * HW + pix_id];
-			dLf0 = dL_dpix_flow[0 * HW + pix_id]; dLf1 = dL_dpix_flow[1 * HW + pix_id];
-			dL_depth = dL_depths[pix_id];
-			dL_mask = dL_masks[pix_id];
+			if (dL_dpixels) { dLp0 = dL_dpixels[0 * HW + pix_id]; dLp1 = dL_dpixels[1 * HW + pix_id]; dLp2 = dL_dpixels[2 * HW + pix_id]; }
+			if (AUX && dL_dpix_flow) { dLf0 = dL_dpix_flow[0 * HW + pix_id]; dLf1 = dL_dpix_flow[1 * HW + pix_id]; }
+			if (AUX && dL_depths) dL_depth = dL_depths[pix_id];
+			if (AUX && dL_masks) dL_mask = dL_masks[pix_id];
 		}
-		const float bg_dot_dpixel = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
+		const float nTf_bg = -T_final * (bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2);
 		const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H; // backward.cu:1010-1011
 
-		// The slot this lane owns after transpose_reduce16 (12 live slots in lanes 0..15) is word `slot` of the
-		// Gaussian's packed 64-byte accumulator record: colour 0-2, flow 3-4, mean2D 5-7, conic xx/xy/yy 8-10,
+		// After row_transpose_reduce12 lane L holds slot (L & 15) = word (L & 15) of the Gaussian's packed 64-byte
+		// accumulator record: colour r,g,b 0-2, depth 3, flow 4-5, mean2D x,y 6-7, conic xx,yy 8-9, conic xy 10,
 		// opacity 11.  One record = one 64-B segment, so the 12-lane atomic instruction is ONE memory-side
 		// request instead of five (the reference scatters into five arrays, backward.cu:1116-1133).
-		const int slot = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-		float* const slot_ptr = gacc + slot;
-		const bool slot_writer = lane < 16 && slot < NG;
+		float* const slot_ptr = gacc + (lane & 15);
+		const bool slot_writer = lane < NG && (AUX || lane < 3 || lane > 5);
 
-		float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accf0 = 0.f, accf1 = 0.f, acc_depth = 0.f, acc_mask = 0.f;
-		float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lf0 = 0.f, lf1 = 0.f, last_depth = 0.f;
+		float S = 0.f, Lc = 0.f, last_alpha = 0.f;
+
+		// One queue entry against this lane's pixel.  (ea, eb, ec) = the packed record, epos = list position.
+		auto entry = [&](const float4 ea, const float4 eb, const float4 ec, const uint32_t epos, const uint32_t eid) __attribute__((always_inline))
+		{
+			const float dx = ea.x - pixfx, dy = ea.y - pixfy;
+			// the reference's own association (forward.cu:585, backward.cu:1036): keeps alpha -- and with it the
+			// alpha >= 1/255 decision -- within an ulp of the oracle's; a cheaper factored form was measured to flip
+			// cliff pairs (2 Gaussians in 30000 off by 1e-3 of the gradient scale) and was dropped
+			const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
+			const float G = fast_exp(power);
+			const float alpha = fminf(0.99f, eb.y * G);
+			// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
+			const bool active = ((int)epos < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+			if (__ballot(active) == 0ull) return;
+			// Branch-free from here: a lane that skips this entry runs the same instructions with
+			// alpha = G = 0, which leaves T and the recurrence unchanged and makes all 12 products zero.
+			const float alpha_e = active ? alpha : 0.0f;
+			const float G_e = active ? G : 0.0f;
+			const float inv = __builtin_amdgcn_rcpf(1.f - alpha_e);
+			T = T * inv;
+			const float dchannel_dcolor = alpha_e * T;
+			// The reference keeps seven "colour behind me" recurrences  acc_k = la * last_k + (1 - la) * acc_k
+			// (rgb, flow, depth, mask; backward.cu:1063-1096) and sums (c_k - acc_k) * dL_k.  All seven share
+			// the coefficients and dL_k is a per-pixel constant, so they collapse into ONE scalar recurrence on
+			// S = sum_k acc_k dL_k with  last = sum_k c_k dL_k  (c_mask = 1):  same value up to fp32 rounding.
+			float Cd;
+			if constexpr (AUX) Cd = fmaf(eb.z, dLp0, fmaf(eb.w, dLp1, fmaf(ec.x, dLp2, fmaf(ec.z, dLf0, fmaf(ec.w, dLf1, fmaf(ec.y, dL_depth, dL_mask))))));
+			else Cd = fmaf(eb.z, dLp0, fmaf(eb.w, dLp1, ec.x * dLp2));
+			S = fmaf(last_alpha, Lc - S, S);
+			Lc = Cd;
+			last_alpha = alpha_e;
+			const float dL_dalpha = fmaf(Cd - S, T, inv * nTf_bg);
+
+			float g[12];
+			g[0] = dchannel_dcolor * dLp0;
+			g[1] = dchannel_dcolor * dLp1;
+			g[2] = dchannel_dcolor * dLp2;
+			if constexpr (AUX)
+			{
+				g[3] = dL_depth * dchannel_dcolor;
+				g[4] = dchannel_dcolor * dLf0;
+				g[5] = dchannel_dcolor * dLf1;
+			}
+			g[11] = G_e * dL_dalpha;
+			{
+				// dG/dd = -G Q d:  t = Q d
+				const float t1 = fmaf(ea.w, dy, ea.z * dx), t2 = fmaf(ea.w, dx, eb.x * dy);
+				const float k = eb.y * g[11];          // dL/dG * G
+				const float kh = -0.5f * k;
+				const float khx = kh * dx;
+				g[6] = (k * t1) * -ddelx_dx;
+				g[7] = (k * t2) * -ddely_dy;
+				g[8] = khx * dx;
+				g[9] = (kh * dy) * dy;
+				g[10] = khx * dy;
+			}
+			reduce_and_add<AUX>(g, slot_ptr, slot_writer, eid);
+		};
 
 		for (int top = wave_last; top > 0; top -= WAVE)
 		{
@@ -158,78 +273,28 @@ namespace fdgs
 				s_pos[q] = (uint32_t)pos;
 				s_id[q] = id;
 			}
-			if (lane == 0)
+			if (lane < 2)
 			{
-				// inert entry behind the queue so the prefetch of entry j+1 never reads stale data
-				s_a[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_b[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_c[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_pos[cnt] = 0x7fffffffu;
-				s_id[cnt] = 0u;
+				// inert entries behind the queue so the prefetch never reads stale data
+				s_a[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_b[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_c[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+				s_pos[cnt + lane] = 0x7fffffffu;
+				s_id[cnt + lane] = 0u;
 			}
 			__syncthreads();
 
-			float4 na = s_a[0], nb = s_b[0], nc = s_c[0];
-			uint32_t npos = s_pos[0], nid = s_id[0];
-			for (int j = 0; j < cnt; j++)
+			// software pipeline: entry j is in registers, entry j+1 is fetched now and lands while j is processed
+			float4 a0 = s_a[0], b0 = s_b[0], c0 = s_c[0];
+			uint32_t p0 = s_pos[0], i0 = s_id[0];
+			for (int j = 0; j < cnt; j += 2)
 			{
-				// software pipeline: entry j is in registers, entry j+1 is fetched now and lands while j is processed
-				const float4 ea = na, eb = nb, ec = nc;
-				const uint32_t epos = npos, eid = nid;
-				na = s_a[j + 1]; nb = s_b[j + 1]; nc = s_c[j + 1];
-				npos = s_pos[j + 1]; nid = s_id[j + 1];
-
-				float g[16];
-#pragma unroll
-				for (int k = 0; k < 16; k++) g[k] = 0.f;
-				const float dx = ea.x - pixfx, dy = ea.y - pixfy;
-				const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-				const float G = fast_exp(power);
-				const float alpha = fminf(0.99f, eb.y * G);
-				// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
-				const bool active = ((int)epos < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-				if (active)
-				{
-					const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-					T = T * inv;
-					const float dchannel_dcolor = alpha * T;
-					float dL_dalpha = 0.0f;
-					const float one_m_la = 1.f - last_alpha;
-					acc0 = last_alpha * lc0 + one_m_la * acc0; lc0 = eb.z; dL_dalpha += (eb.z - acc0) * dLp0;
-					acc1 = last_alpha * lc1 + one_m_la * acc1; lc1 = eb.w; dL_dalpha += (eb.w - acc1) * dLp1;
-					acc2 = last_alpha * lc2 + one_m_la * acc2; lc2 = ec.x; dL_dalpha += (ec.x - acc2) * dLp2;
-					accf0 = last_alpha * lf0 + one_m_la * accf0; lf0 = ec.z; dL_dalpha += (ec.z - accf0) * dLf0;
-					accf1 = last_alpha * lf1 + one_m_la * accf1; lf1 = ec.w; dL_dalpha += (ec.w - accf1) * dLf1;
-					acc_depth = last_alpha * last_depth + one_m_la * acc_depth; last_depth = ec.y;
-					dL_dalpha += (ec.y - acc_depth) * dL_depth;
-					acc_mask = last_alpha + one_m_la * acc_mask;
-					dL_dalpha += (1.0f - acc_mask) * dL_mask;
-					dL_dalpha *= T;
-					last_alpha = alpha;
-					dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-
-					const float dL_dG = eb.y * dL_dalpha;
-					const float gdx = G * dx, gdy = G * dy;
-					const float dG_ddelx = -gdx * ea.z - gdy * ea.w;
-					const float dG_ddely = -gdy * eb.x - gdx * ea.w;
-					g[0] = dchannel_dcolor * dLp0;
-					g[1] = dchannel_dcolor * dLp1;
-					g[2] = dchannel_dcolor * dLp2;
-					g[3] = dchannel_dcolor * dLf0;
-					g[4] = dchannel_dcolor * dLf1;
-					g[5] = dL_dG * dG_ddelx * ddelx_dx;
-					g[6] = dL_dG * dG_ddely * ddely_dy;
-					g[7] = dL_depth * dchannel_dcolor;
-					g[8] = -0.5f * gdx * dx * dL_dG;
-					g[9] = -0.5f * gdx * dy * dL_dG;
-					g[10] = -0.5f * gdy * dy * dL_dG;
-					g[11] = G * dL_dalpha;
-				}
-				if (__ballot(active) != 0ull)
-				{
-					const float total = transpose_reduce16(g, lane);
-					if (slot_writer) atomicAdd(slot_ptr + (size_t)eid * GRAD_ACC_WORDS, total);
-				}
+				// unrolled by two with ping-pong register sets: no register rotation between iterations
+				const float4 a1 = s_a[j + 1], b1 = s_b[j + 1], c1 = s_c[j + 1];
+				const uint32_t p1 = s_pos[j + 1], i1 = s_id[j + 1];
+				entry(a0, b0, c0, p0, i0);
+				a0 = s_a[j + 2]; b0 = s_b[j + 2]; c0 = s_c[j + 2]; p0 = s_pos[j + 2]; i0 = s_id[j + 2];
+				entry(a1, b1, c1, p1, i1); // the inert padding entry when j + 1 == cnt: skipped by its own test
 			}
 			__syncthreads();
 		}
@@ -241,11 +306,13 @@ namespace fdgs
 	{
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
 		const int ntiles = gx * gy;
-		hipLaunchKernelGGL(blend_bwd_kernel, dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream,
-		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records),
-		                   s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib,
-		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow,
-		                   out.grad_accum);
+#define LAUNCH_BWD(AUX) hipLaunchKernelGGL((blend_bwd_kernel<AUX>), dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream, \
+		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records), \
+		                   s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib, \
+		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow, out.grad_accum)
+		if (in.dL_dout_depth || in.dL_dout_alpha || in.dL_dout_flow) LAUNCH_BWD(true);
+		else LAUNCH_BWD(false);
+#undef LAUNCH_BWD
 		return hipGetLastError();
 	}
 }

@@ -251,7 +251,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	const bool debug = s.debug != 0;
 	const int P = s.P, W = s.W, H = s.H;
 	if (P == 0) return FDGS_OK;
-	if (!in->dL_dout_color || !in->dL_dout_depth || !in->dL_dout_alpha || !in->dL_dout_flow ||
+	if ((!in->dL_dout_color && !in->dL_dout_depth && !in->dL_dout_alpha && !in->dL_dout_flow) ||
 	    !in->radii || !in->out_means3D || !in->geom_buffer || !in->binning_buffer || !in->image_buffer)
 		return fail(FDGS_ERR_INVALID_ARG, "backward inputs must not be NULL");
 	if (!out->dL_dmeans2D || !out->dL_dcolors || !out->dL_dopacity || !out->dL_dmeans3D || !out->dL_dcov3D ||

@@ -70,13 +70,14 @@ namespace fdgs
 		float3 dscale = make_float3(0, 0, 0);
 		float dscale_t = 0.f;
 		float4 drot = make_float4(0, 0, 0, 0), drot_r = make_float4(0, 0, 0, 0);
-		// unpack the accumulator record: colour 0-2, flow 3-4, mean2D 5-7, conic xx/xy/yy 8-10, opacity 11
+		// unpack the accumulator record (blend_bwd.hip): colour 0-2, depth 3, flow 4-5, mean2D x,y 6-7,
+		// conic xx 8, yy 9, xy 10, opacity 11, SH-backward mean/time 12-15
 		const float4* rec = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS);
 		const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
 		const float3 g_color = make_float3(r0.x, r0.y, r0.z);
-		const float2 g_flow = make_float2(r0.w, r1.x);
-		const float3 g_mean2D = make_float3(r1.y, r1.z, r1.w);
-		const float3 g_conic = make_float3(r2.x, r2.y, r2.z);
+		const float2 g_flow = make_float2(r1.x, r1.y);
+		const float3 g_mean2D = make_float3(r1.z, r1.w, r0.w);
+		const float3 g_conic = make_float3(r2.x, r2.z, r2.y);
 		float g_opacity = r2.w;
 
 		if (visible)

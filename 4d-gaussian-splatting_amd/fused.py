@@ -37,7 +37,7 @@ class _RasterizeRaw(torch.autograd.Function):
         ctx.save_for_backward(means3D, out_means3D, scaling_raw, rotation_raw, radii, sh, opacity_raw, ts, scaling_t_raw,
                               rotation_r_raw, geom, binb, img)
         ctx.mark_non_differentiable(radii)
-        ctx.set_materialize_grads(True)
+        ctx.set_materialize_grads(False)  # unused outputs -> None gradients -> colour-only backward
         return color, radii, depth, 1 - T, flow
 
     @staticmethod

@@ -133,7 +133,13 @@ class _NativeRasterizer:
         preallocated contiguous tensors the kernels write into (e.g. views of a flat gradient bucket);
         ``accumulate``: the kernels ADD into those parameter gradients instead of overwriting them."""
         dev = means3D.device
-        H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])  # rasterize_points.cu:192-193
+        # The reference always receives four dense tensors (autograd materialises zeros).  Here an image gradient may
+        # be None = "no upstream gradient": the kernels then skip that term (colour-only backward when only
+        # dL_dout_color is given, the usual photometric-loss case).
+        given = [t for t in (dL_dout_color, dL_dout_depth, dL_dout_mask, dL_dout_flow) if t is not None]
+        if not given:
+            raise RuntimeError("fdgs: backward needs at least one upstream image gradient")
+        H, W = int(given[0].shape[1]), int(given[0].shape[2])  # rasterize_points.cu:192-193
         scene, keep = self._scene(bg, means3D, colors, flows_2d, opacities, ts, scales, scales_t, rotations,
                                   rotations_r, scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix,
                                   tan_fovx, tan_fovy, H, W, sh, degree, degree_t, campos, timestamp, time_duration,
@@ -161,7 +167,7 @@ class _NativeRasterizer:
         gin = [_capi._dev_f32(t, n) for t, n in ((dL_dout_color, "dL_dout_color"), (dL_dout_depth, "dL_dout_depth"),
                                                  (dL_dout_mask, "dL_dout_mask"), (dL_dout_flow, "dL_dout_flow"))]
         radii_c, om_c = radii.contiguous(), out_means3D.contiguous()
-        bin_ = _capi.FdgsBackwardIn(gin[0].data_ptr(), gin[1].data_ptr(), gin[2].data_ptr(), gin[3].data_ptr(),
+        bin_ = _capi.FdgsBackwardIn(_capi._ptr(gin[0]), _capi._ptr(gin[1]), _capi._ptr(gin[2]), _capi._ptr(gin[3]),
                                     _capi._ptr(radii_c), _capi._ptr(om_c), _capi._ptr(geomBuffer),
                                     _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R))
         if accumulate and not grad_out:
@@ -258,6 +264,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.prefilter_var = prefilter_var
         ctx.save_for_backward(colors_precomp, means3D, out_means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               flow_2d, opacities, ts, scales_t, rotations_r, geomBuffer, binningBuffer, imgBuffer)
+        # outputs nobody differentiates arrive as None in backward instead of dense zeros (see the native binding)
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, 1 - T, flow, covs_com
 
@@ -266,6 +274,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, out_means3D, scales, rotations, cov3Ds_precomp, radii, sh, flow_2d, opacities, ts,
          scales_t, rotations_r, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None and grad_depth is None and grad_alpha is None and grad_flow is None:
+            # only covs_com was differentiated: the reference ignores that gradient, the images contribute zeros
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         native_args = (
             rs.bg, means3D, out_means3D, radii, colors_precomp, flow_2d, opacities, ts, scales, scales_t, rotations,
             rotations_r, rs.scale_modifier, cov3Ds_precomp, ctx.prefilter_var, rs.viewmatrix, rs.projmatrix,

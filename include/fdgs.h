@@ -115,7 +115,9 @@ typedef struct fdgs_forward_out
 	                         (zero for culled Gaussians; the reference returns uninitialised memory there) */
 } fdgs_forward_out;
 
-/* Upstream gradients (d loss / d forward outputs). */
+/* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output
+   has no upstream gradient" (treated as zero; at least one must be given).  With only dL_dout_color given the
+   backward blend runs its colour-only variant. */
 typedef struct fdgs_backward_in
 {
 	const float* dL_dout_color;  /* [3,H,W]                                        */

@@ -93,3 +93,16 @@ def test_c2_full_size(gpu_device):
     repg = check_backward(hipg, refg, "C2")
     print("C2 R", ref["R"], rep)
     print("C2", {k: "%.2e/%.1e" % v for k, v in repg.items()})
+
+
+@pytest.mark.parametrize("name", ["rot4d_sh3_t2", "C1_rot4d_sh0", "ragged_33x17"])
+def test_colour_only_backward_vs_oracle(name, gpu_device):
+    """Only the colour image has an upstream gradient (depth / alpha / flow gradients None at the binding, NULL at
+    the C ABI): the colour-only blend-backward variant must equal the oracle fed with explicit zeros."""
+    scene = _scene(name)
+    grads = synth.make_upstream_grads(scene["W"], scene["H"], seed=3, scale=GRAD_SCALE)
+    zeros = {k: (v if k == "grad_color" else torch.zeros_like(v)) for k, v in grads.items()}
+    nones = {k: (v if k == "grad_color" else None) for k, v in grads.items()}
+    _, hipg = run_hip(scene, gpu_device, nones)
+    _, refg = run_oracle(scene, zeros, kind="port")
+    check_backward(hipg, refg, name + " colour-only")

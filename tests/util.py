@@ -84,7 +84,7 @@ def run_hip(scene, device, grads=None):
     if grads is not None:
         e = torch.Tensor([])
         g = lambda k: sc[k] if sc.get(k) is not None else e  # noqa: E731
-        gd = {k: t.to(device) for k, t in grads.items()}
+        gd = {k: (t.to(device) if t is not None else None) for k, t in grads.items()}  # None = no upstream gradient
         bargs = (sc["bg"], sc["means3D"], out_means3D, radii, g("colors_precomp"), g("flow_2d"), sc["opacities"],
                  g("ts"), g("scales"), g("scales_t"), g("rotations"), g("rotations_r"), sc.get("scale_modifier", 1.0),
                  g("cov3D_precomp"), sc.get("prefilter_var", -1.0), sc["world_view_transform"],
