@@ -161,9 +161,19 @@ def current_stream_handle(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def profile_enable(on: bool = True):
-    """Bracket every stage with HIP events on the caller's stream (fdgs_profile_enable)."""
-    lib.fdgs_profile_enable(1 if on else 0)
+def profile_enable(on: bool = True, stages=None):
+    """Bracket stages with HIP events on the caller's stream (fdgs_profile_enable).  ``stages``: iterable of stage
+    names to restrict the events to (each event pair costs a few microseconds of device idle time)."""
+    if not on:
+        mask = 0
+    elif stages is None:
+        mask = -1
+    else:
+        names = [lib.fdgs_stage_name(i).decode() for i in range(NUM_STAGES)]
+        mask = 0
+        for s in stages:
+            mask |= 1 << names.index(s)
+    lib.fdgs_profile_enable(mask)
 
 
 def profile_reset():

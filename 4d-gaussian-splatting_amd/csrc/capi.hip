@@ -45,7 +45,7 @@ namespace
 		long long samples = 0;
 	};
 	// process-wide (autograd runs the backward on its own thread); guarded by g_prof_mu
-	std::atomic<bool> g_prof_on{false};
+	std::atomic<uint32_t> g_prof_mask{0};   // bit i: stage i is bracketed with events
 	StageProf g_prof[FDGS_NUM_STAGES];
 	std::mutex g_prof_mu;
 
@@ -70,7 +70,7 @@ namespace
 		bool locked = false;
 		StageTimer(int stage, hipStream_t s) : stream(s)
 		{
-			if (!g_prof_on.load(std::memory_order_relaxed)) return;
+			if (!((g_prof_mask.load(std::memory_order_relaxed) >> stage) & 1u)) return;
 			g_prof_mu.lock();
 			locked = true;
 			p = &g_prof[stage];
@@ -97,7 +97,7 @@ namespace
 		"tile_sort", "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero", "sh_bwd" };
 }
 
-extern "C" int fdgs_profile_enable(int on) { g_prof_on.store(on != 0); return FDGS_OK; }
+extern "C" int fdgs_profile_enable(int stage_mask) { g_prof_mask.store((uint32_t)stage_mask); return FDGS_OK; }
 extern "C" int fdgs_profile_reset(void)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -215,7 +215,7 @@ int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
 #define FDGS_STAGE_GRAD_ZERO 9
 #define FDGS_STAGE_SH_BWD 10
 #define FDGS_NUM_STAGES 11
-int fdgs_profile_enable(int on);
+int fdgs_profile_enable(int stage_mask); /* bit i set: bracket stage i with HIP events; 0 = off, -1 = all stages */
 int fdgs_profile_read(int stage, double* total_ms, int64_t* samples);
 int fdgs_profile_reset(void);
 const char* fdgs_stage_name(int stage);
