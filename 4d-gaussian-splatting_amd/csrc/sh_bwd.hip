@@ -158,18 +158,18 @@ namespace fdgs
 		}
 	}
 
-	__global__ void __launch_bounds__(256) sh_bwd_kernel(const ShBwdArgs a)
+	// One wave per workgroup: the tile is wave-private, so no workgroup barrier is needed anywhere (LDS
+	// operations of one wave execute in order) and waves of different phases (load / compute / store) overlap freely.
+	__global__ void __launch_bounds__(WAVE) sh_bwd_kernel(const ShBwdArgs a)
 	{
-		__shared__ float s_tile[256 / WAVE][WAVE * SHB_STRIDE];
-		const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-		float* tile = s_tile[wave];
+		__shared__ float tile[WAVE * SHB_STRIDE];
+		const int lane = threadIdx.x;
 		float* row = tile + lane * SHB_STRIDE;
-		const int g0 = blockIdx.x * blockDim.x + wave * WAVE;
+		const int g0 = blockIdx.x * WAVE;
 		const int tid_g = g0 + lane;
 		const bool valid = tid_g < a.P;
 		const int idx = valid ? tid_g : a.P - 1;
 		const bool visible = valid && a.radii[idx] > 0; // backward.cu:873
-		const unsigned long long vmask = __ballot(visible);
 		const size_t row_floats = (size_t)3 * a.M;
 
 		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
@@ -187,6 +187,11 @@ namespace fdgs
 		if (cl & 1) dRGB.x = 0.f;   // clamped channels get no gradient (backward.cu:158-161)
 		if (cl & 2) dRGB.y = 0.f;
 		if (cl & 4) dRGB.z = 0.f;
+		// Every output of this kernel is linear in dRGB.  A Gaussian that is visible but contributed to no pixel
+		// (occluded, or too faint everywhere: 58 % of the visible ones on the C3 workload) has dRGB == 0 exactly:
+		// its coefficients are not read and its gradient row is zero (not touched at all when accumulating).
+		const bool live = visible && (dRGB.x != 0.f || dRGB.y != 0.f || dRGB.z != 0.f);
+		const unsigned long long vmask = __ballot(live);
 		const float dir_t = sh3d ? 0.f : a.ts[idx] - a.timestamp;
 		float l[16], dX[16], dY[16], dZ[16];
 		sh_tables(a.D, dir.x, dir.y, dir.z, !sh3d, l, dX, dY, dZ);
@@ -199,8 +204,8 @@ namespace fdgs
 			const bool vec = a.vec_ok && nk == 16;
 			if (vec) tile_load16(tile, a.shs, g0, a.P, row_floats, first_float, vmask, lane);
 			else tile_load_any(tile, a.shs, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane);
-			__syncthreads();
-			if (visible)
+			__builtin_amdgcn_wave_barrier();
+			if (live)
 			{
 				float tk = 1.f, dtk_dt = 0.f;
 				if (blk == 1)
@@ -235,10 +240,10 @@ namespace fdgs
 					gt = s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
 				}
 			}
-			__syncthreads();
+			__builtin_amdgcn_wave_barrier();
 			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
 			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
-			__syncthreads();
+			__builtin_amdgcn_wave_barrier();
 		}
 		// coefficients above the active degree get a zero gradient (nothing to add when accumulating)
 		if (!a.accum)
@@ -252,7 +257,7 @@ namespace fdgs
 		if (valid)
 		{
 			float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (visible)
+			if (live)
 			{
 				const float3 ddir = make_float3(s_dot(gx, dRGB), s_dot(gy, dRGB), s_dot(gz, dRGB));
 				// dnormvdv, auxiliary.h:108-118
@@ -281,7 +286,7 @@ namespace fdgs
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
-		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, WAVE)), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
 	}
 }
