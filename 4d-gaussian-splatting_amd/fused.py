@@ -22,17 +22,55 @@ import torch
 from .gaussian_renderer.diff_gaussian_rasterization import GaussianRasterizationSettings, _C, _is_given
 
 
+def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var):
+    """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple."""
+    e = torch.Tensor([])
+    args = (rs.bg, means3D, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
+            rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+            rs.image_height, rs.image_width, sh, rs.sh_degree, rs.sh_degree_t, rs.campos, rs.timestamp,
+            rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, rs.prefiltered, rs.debug)
+    return _C.rasterize_gaussians(*args, raw_params=True)
+
+
+def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
+                 prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate):
+    """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple."""
+    e = torch.Tensor([])
+    args = (rs.bg, means3D, out_means3D, radii, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
+            rotation_r_raw, rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, g_color, g_depth, g_alpha, g_flow, sh, rs.sh_degree, rs.sh_degree_t, rs.campos,
+            rs.timestamp, rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, geom, R, binb, img, rs.debug)
+    return _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=accumulate)
+
+
+def raw_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0):
+    """GaussianRasterizationSettings + the raw parameter tensors of ``pc`` for the default pipeline."""
+    if pipe.compute_cov3D_python or pipe.convert_SHs_python or pipe.env_map_res:
+        raise ValueError("render_raw covers the default pipeline only; use render() for the Python covariance / SH / env-map branches")
+    rs = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        sh_degree_t=pc.active_sh_degree_t, campos=viewpoint_camera.camera_center, timestamp=viewpoint_camera.timestamp,
+        time_duration=pc.time_duration[1] - pc.time_duration[0], rot_4d=pc.rot_4d, gaussian_dim=pc.gaussian_dim,
+        force_sh_3d=pc.force_sh_3d, prefiltered=False, debug=pipe.debug)
+    e = torch.Tensor([])
+    is_4d = pc.gaussian_dim == 4
+    ts = pc._t if is_4d else e
+    scaling_t = pc._scaling_t if is_4d else e
+    rotation_r = pc._rotation_r if (is_4d and pc.rot_4d) else e
+    prefilter_var = pc.prefilter_var if (is_4d and pc.prefilter_var > 0.0) else -1.0
+    return rs, (pc._xyz, pc.get_features, pc._opacity, ts, pc._scaling, scaling_t, pc._rotation, rotation_r, prefilter_var)
+
+
 class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
                 prefilter_var, raster_settings, grad_sink, accumulate):
         rs = raster_settings
-        e = torch.Tensor([])
-        args = (rs.bg, means3D, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
-                rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
-                rs.image_height, rs.image_width, sh, rs.sh_degree, rs.sh_degree_t, rs.campos, rs.timestamp,
-                rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, rs.prefiltered, rs.debug)
-        (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = _C.rasterize_gaussians(*args, raw_params=True)
+        (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = raw_forward(
+            rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
         ctx.rs, ctx.R, ctx.prefilter_var, ctx.sink, ctx.accumulate = rs, R, prefilter_var, grad_sink, bool(accumulate)
         ctx.save_for_backward(means3D, out_means3D, scaling_raw, rotation_raw, radii, sh, opacity_raw, ts, scaling_t_raw,
                               rotation_r_raw, geom, binb, img)
@@ -45,15 +83,11 @@ class _RasterizeRaw(torch.autograd.Function):
         rs = ctx.rs
         (means3D, out_means3D, scaling_raw, rotation_raw, radii, sh, opacity_raw, ts, scaling_t_raw, rotation_r_raw,
          geom, binb, img) = ctx.saved_tensors
-        e = torch.Tensor([])
-        args = (rs.bg, means3D, out_means3D, radii, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
-                rotation_r_raw, rs.scale_modifier, e, ctx.prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
-                rs.tanfovy, g_color, g_depth, g_alpha, g_flow, sh, rs.sh_degree, rs.sh_degree_t, rs.campos,
-                rs.timestamp, rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, geom, ctx.R, binb, img,
-                rs.debug)
         sink = ctx.sink
         (d_means2D, _d_colors, d_opacity, d_means3D, _d_cov3D, d_sh, _d_flows, d_ts, d_scales, d_scales_t, d_rot,
-         d_rot_r) = _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=ctx.accumulate)
+         d_rot_r) = raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
+                                 rotation_r_raw, ctx.prefilter_var, geom, ctx.R, binb, img, g_color, g_depth, g_alpha, g_flow,
+                                 sink, ctx.accumulate)
 
         def ret(name, given, g):
             if not _is_given(given):
@@ -71,27 +105,11 @@ class _RasterizeRaw(torch.autograd.Function):
 
 def render_raw(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, grad_sink=None, accumulate=False):
     """``render()`` with the activations fused into the kernels; see the module docstring."""
-    if pipe.compute_cov3D_python or pipe.convert_SHs_python or pipe.env_map_res:
-        raise ValueError("render_raw covers the default pipeline only; use render() for the Python covariance / SH / env-map branches")
-    xyz = pc._xyz
-    device = xyz.device
+    rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
+        viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     screenspace_points = torch.zeros_like(xyz, requires_grad=True)
-    rs = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
-        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
-        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
-        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
-        sh_degree_t=pc.active_sh_degree_t, campos=viewpoint_camera.camera_center, timestamp=viewpoint_camera.timestamp,
-        time_duration=pc.time_duration[1] - pc.time_duration[0], rot_4d=pc.rot_4d, gaussian_dim=pc.gaussian_dim,
-        force_sh_3d=pc.force_sh_3d, prefiltered=False, debug=pipe.debug)
-    e = torch.Tensor([])
-    is_4d = pc.gaussian_dim == 4
-    ts = pc._t if is_4d else e
-    scaling_t = pc._scaling_t if is_4d else e
-    rotation_r = pc._rotation_r if (is_4d and pc.rot_4d) else e
-    prefilter_var = pc.prefilter_var if (is_4d and pc.prefilter_var > 0.0) else -1.0
     color, radii, depth, alpha, flow = _RasterizeRaw.apply(
-        xyz, screenspace_points, pc.get_features, pc._opacity, ts, pc._scaling, scaling_t, pc._rotation, rotation_r,
+        xyz, screenspace_points, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r,
         prefilter_var, rs, grad_sink, accumulate)
     return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth": depth, "alpha": alpha, "flow": flow}

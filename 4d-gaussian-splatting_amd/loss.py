@@ -51,3 +51,26 @@ class _FusedL1SSIM(torch.autograd.Function):
 def fused_l1_ssim(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
     """(1 - lambda) * L1(image, gt) + lambda * (1 - SSIM(image, gt)); image, gt: [3, H, W] on the GPU."""
     return _FusedL1SSIM.apply(image, gt, lambda_dssim)
+
+
+def l1_ssim_value_and_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor):
+    """The same loss without autograd: returns ``(loss, d(upstream * loss)/d image)``.  ``upstream`` is a 1-element
+    float32 GPU tensor (e.g. 1 / batch_size).  Both kernels are enqueued on the current stream."""
+    if not image.is_cuda or not gt.is_cuda:
+        raise RuntimeError("fdgs: l1_ssim_value_and_grad needs GPU tensors; there is no CPU path")
+    img_c, gt_c = image.contiguous().float(), gt.contiguous().float()
+    C, H, W = img_c.shape[-3], img_c.shape[-2], img_c.shape[-1]
+    dev = img_c.device
+    d1, d2, d3, g = (torch.empty_like(img_c) for _ in range(4))
+    nparts = _capi.lib.fdgs_l1_ssim_num_partials(C, H, W)
+    parts = torch.empty((2, nparts), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _capi.current_stream_handle(dev)
+        rc = _capi.lib.fdgs_l1_ssim_forward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
+                                            d3.data_ptr(), parts[0].data_ptr(), parts[1].data_ptr(), st)
+        _capi._check(rc, "fdgs_l1_ssim_forward")
+        rc = _capi.lib.fdgs_l1_ssim_backward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
+                                             d3.data_ptr(), upstream.data_ptr(), float(lambda_dssim), g.data_ptr(), st)
+        _capi._check(rc, "fdgs_l1_ssim_backward")
+    sums = parts.sum(dim=1) / float(C * H * W)
+    return (1.0 - lambda_dssim) * sums[0] + lambda_dssim * (1.0 - sums[1]), g

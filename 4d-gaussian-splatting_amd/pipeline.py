@@ -1,0 +1,86 @@
+"""One optimizer step = the B views of a batch on two HIP streams (MI355X: overlap instead of a longer queue).
+
+Within one optimizer step the parameters are constant, so the forward of view b+1 does not depend on the backward
+of view b (reference train.py:104-170 runs them strictly one after the other through autograd).  The forward front
+end is a chain of short latency-bound kernels (preprocess, two radix sorts, scans: HBM / launch latency) while the
+backward is dominated by the VALU-bound blend kernel: run on two streams they fill each other's gaps.
+
+    stream F : fwd(0)         fwd(1)         fwd(2) ...
+    stream B :        loss+bwd(0)    loss+bwd(1)    ...   all-reduce, Adam
+
+No autograd: forward, fused L1+SSIM (value and gradient) and backward are called explicitly; parameter gradients
+are written (view 0) / added (views 1..) straight into the flat bucket (``GaussianParams.grad_sink``), the loss is
+pre-scaled by 1 / (B * world) so that the all-reduce SUM is already the mean.  Same arithmetic as
+``render_raw`` + ``fused_l1_ssim`` + ``backward()`` per view (tests/test_gpu_api.py compares the two).
+"""
+from typing import List, Sequence
+
+import torch
+
+from .fused import raw_backward, raw_forward, raw_settings
+from .loss import l1_ssim_value_and_grad
+from .train_host import allreduce_gradients
+
+
+class StepPipeline:
+    def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True):
+        self.model, self.opt, self.world, self.lam = model, optimizer, int(world_size), float(lambda_dssim)
+        dev = model.flat.device
+        self.dev = dev
+        # (Tried and dropped, with measurements on MI355X: a high-priority F stream and a CU-masked B stream change
+        # nothing or hurt; persistent blend kernels that leave wave slots free for the other stream lose more to
+        # load imbalance / ~100 ns same-address atomics than the overlap returns.  See DESIGN.md.)
+        self.sF = torch.cuda.Stream(dev)
+        self.sB = torch.cuda.Stream(dev) if overlap else self.sF
+        self.sink = model.grad_sink()
+        self._up = {}
+
+    def _upstream(self, B):
+        if B not in self._up:
+            self._up[B] = torch.full((1,), 1.0 / (B * self.world), dtype=torch.float32, device=self.dev)
+        return self._up[B]
+
+    def step(self, cams: Sequence, gts: Sequence[torch.Tensor], pipe, bg: torch.Tensor, scaling_modifier: float = 1.0):
+        """Runs forward + loss + backward of every view, the gradient all-reduce and the optimizer step.
+        Returns (list of per-view results dict(render, radii, depth, alpha, flow, viewspace_grad), list of losses)."""
+        B = len(cams)
+        main = torch.cuda.current_stream(self.dev)
+        self.sF.wait_stream(main)
+        if self.sB is not self.sF:
+            self.sB.wait_stream(main)
+        up = self._upstream(B)
+        m = self.model
+        results, losses, keep = [], [], []
+        for b in range(B):
+            with torch.cuda.stream(self.sF):
+                rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
+                    cams[b], m, pipe, bg, scaling_modifier)
+                (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
+                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var)
+                ev = torch.cuda.Event()
+                ev.record(self.sF)
+            with torch.cuda.stream(self.sB):
+                self.sB.wait_event(ev)
+                loss, g_color = l1_ssim_value_and_grad(color, gts[b], self.lam, up)
+                grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
+                                     rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
+                                     self.sink, b > 0)
+            # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
+            keep.append((geom, binb, img, out_means3D, g_color, T))
+            results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow,
+                            "viewspace_grad": grads[0], "num_rendered": R})
+            losses.append(loss)
+        with torch.cuda.stream(self.sB):
+            allreduce_gradients(m, self.world, average=False)  # the losses were scaled by 1 / (B * world)
+            self.opt.step()
+        main.wait_stream(self.sB)
+        main.wait_stream(self.sF)
+        self.sF.wait_stream(self.sB)
+        for r in results:  # handed to the caller, who works on `main`
+            for t in r.values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        for l in losses:
+            l.record_stream(main)
+        del keep
+        return results, losses

@@ -170,12 +170,15 @@ def make_optimizer(model: GaussianParams) -> FlatAdam:
     return FlatAdam(model)
 
 
-def allreduce_gradients(model: GaussianParams, world_size: int) -> None:
-    """One collective over the flat gradient bucket; grads become the mean over ranks (loss / batch_size)."""
+def allreduce_gradients(model: GaussianParams, world_size: int, average: bool = True) -> None:
+    """One collective over the flat gradient bucket; grads become the mean over ranks (loss / batch_size).
+    ``average=False``: plain SUM, for callers that already scaled their loss by 1 / world_size (saves one pass
+    over the bucket)."""
     if world_size > 1:
         import torch.distributed as dist
         dist.all_reduce(model.flat_grad, op=dist.ReduceOp.SUM)
-        model.flat_grad.mul_(1.0 / world_size)
+        if average:
+            model.flat_grad.mul_(1.0 / world_size)
 
 
 # ------------------------- utils/loss_utils.py:17-64 -------------------------

@@ -68,6 +68,10 @@ def parse_args():
     ap.add_argument("--reference-host", action="store_true",
                     help="host side exactly as the reference: render() on PyTorch activations, autograd gradient accumulation")
     ap.add_argument("--torch-loss", action="store_true", help="L1 + SSIM through PyTorch conv2d (MIOpen) instead of the fused HIP kernel")
+    ap.add_argument("--autograd", action="store_true",
+                    help="fused kernels driven through autograd (render_raw + fused_l1_ssim + backward()) on one stream, "
+                         "instead of the explicit two-stream step pipeline (fdgs/pipeline.py)")
+    ap.add_argument("--no-overlap", action="store_true", help="step pipeline on a single stream (A/B for the overlap)")
     return ap.parse_args()
 
 
@@ -169,8 +173,15 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(dev) for _ in range(B)]
     sink = None if args.reference_host else model.grad_sink()
+    use_pipeline = not (args.reference_host or args.autograd or args.torch_loss or args.no_loss)
+    if use_pipeline:
+        from fdgs.pipeline import StepPipeline
+        steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap)
 
     def step():
+        if use_pipeline:
+            results, _losses = steppipe.step(cams, gts, pipe, bg)
+            return results[-1]
         if args.reference_host:
             model.zero_grad()
         pkg = None
@@ -186,8 +197,8 @@ def main():
                 loss = train_host.photometric_loss(pkg["render"], gts[b])
             else:
                 loss = fused_l1_ssim(pkg["render"], gts[b], 0.2)
-            (loss / B).backward()  # train.py:162
-        train_host.allreduce_gradients(model, world)
+            (loss / (B * world)).backward()  # train.py:162; 1 / world: the all-reduce SUM is then the mean
+        train_host.allreduce_gradients(model, world, average=False)
         opt.step()
         return pkg
 
@@ -271,7 +282,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
-                                                                        M, cfg.rot_4d, B, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else ", fused activations"),
+                                                                        M, cfg.rot_4d, B, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else (", fused activations, explicit fwd/loss/bwd on %s" % ("one stream" if args.no_overlap else "two HIP streams") if use_pipeline else ", fused activations, autograd")),
                    "num_rendered": R, "visible": Pv, "views_per_step_per_gpu": B, "global_batch": B * world,
                    "parallelism": "frame-parallel dp%d" % world},
         "forward_mpix_s": round(world * n_fwd * N / dt_fwd / 1e6, 1),

@@ -213,3 +213,48 @@ def test_gradient_accumulation_over_views(gpu_device):
     err = (m.flat_grad - want).abs()
     scale = max(1.0, want.abs().max().item())
     assert (err > 1e-4 * scale).float().mean().item() <= 1e-4 and err.max().item() <= 1e-2 * scale, err.max().item()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_step_pipeline_matches_autograd_step(gpu_device, overlap):
+    """fdgs.pipeline.StepPipeline (explicit forward / fused loss / backward on two HIP streams, no autograd) performs
+    the same optimizer step as render_raw + fused_l1_ssim + backward() + Adam on one stream."""
+    from fdgs import train_host
+    from fdgs.fused import render_raw
+    from fdgs.loss import fused_l1_ssim
+    from fdgs.pipeline import StepPipeline
+    cfg = synth.SceneConfig("pipe", 6000, 208, 160, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=4)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    pipe = train_host.PipelineFlags()
+    B = 3
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / B * scene["time_duration"]) for b in range(B)]
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(gpu_device) for _ in range(B)]
+
+    ma = train_host.GaussianParams(scene, gpu_device)
+    oa = train_host.make_optimizer(ma)
+    sink = ma.grad_sink()
+    ref_losses = []
+    for _ in range(2):  # two optimizer steps
+        for b in range(B):
+            loss = fused_l1_ssim(render_raw(cams[b], ma, pipe, bg, grad_sink=sink, accumulate=b > 0)["render"], gts[b], 0.2)
+            (loss / B).backward()
+            ref_losses.append(float(loss))
+        oa.step()
+
+    mp = train_host.GaussianParams(scene, gpu_device)
+    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap)
+    got_losses = []
+    for _ in range(2):
+        results, losses = sp.step(cams, gts, pipe, bg)
+        got_losses += [float(l) for l in losses]
+        assert len(results) == B and results[0]["render"].shape == (3, scene["H"], scene["W"])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-5, atol=1e-6)
+    # the gradients of the last step (float atomics: summation order differs run to run) and the parameters after two steps
+    gerr = (mp.flat_grad - ma.flat_grad).abs()
+    gscale = max(1e-6, ma.flat_grad.abs().max().item())
+    assert gerr.max().item() <= 1e-3 * gscale, (gerr.max().item(), gscale)
+    perr = (mp.flat - ma.flat).abs().max().item()
+    assert perr <= 2e-3, perr  # Adam's first steps move every parameter by ~lr regardless of the gradient magnitude
