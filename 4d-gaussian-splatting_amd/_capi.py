@@ -71,7 +71,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_profile_enable", "fdgs_profile_read",
-            "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward",
+            "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
 
@@ -112,6 +112,8 @@ def _load():
     lib.fdgs_l1_ssim_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     lib.fdgs_l1_ssim_backward.restype = C.c_int
+    lib.fdgs_l1_ssim_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    lib.fdgs_l1_ssim_loss.restype = C.c_int
     lib.fdgs_l1_ssim_num_partials.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.fdgs_l1_ssim_num_partials.restype = C.c_int
     lib.fdgs_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -5,94 +5,128 @@
 // C1 = 0.01^2, C2 = 0.03^2, mean over all pixels and channels).  The reference runs it as five
 // grouped 11x11 convolutions forward plus their backward through the DL library; on ROCm that
 // is ~7.6 ms per 1352x1014 image, four times the whole rasterizer.  Here:
-//   forward : one pass.  A 16x16 output tile loads its 26x26 halo of both images into LDS, does
+//   forward : one pass.  A 32x16 output tile loads its 42x26 halo of both images into LDS as (x, y) pairs, does
 //             the separable window (horizontal, then vertical) for the five moments
 //             (x, y, x^2, y^2, xy), evaluates SSIM and the three partial derivatives
 //             d ssim/d mu1, d ssim/d E[x^2], d ssim/d E[xy] per pixel (kept for the backward),
 //             and writes per-tile partial sums of |x-y| and ssim (summed by the host: deterministic).
+//             The kernel is VALU-issue bound (SQ counters), so it is written for instruction count: the
+//             moments travel as pairs (x,y) (x^2,y^2) + xy -> three packed-fp32 FMAs per tap instead of five;
+//             a thread produces 4 adjacent outputs of the horizontal pass (14 b128-loaded inputs instead of
+//             44 scalar reads) and 2 of the vertical pass.
 //   backward: dL/dx(p) = w_l1 sign(x-y) + w_ssim [ (W * dmu1)(p) + 2 x(p) (W * dE11)(p) + y(p) (W * dE12)(p) ]
 //             -- three more separable windows over the stored derivative maps (W symmetric).
-// Pure streaming fp32 work: ~70 B/pixel-channel forward, ~60 B backward; HBM-bound, no MFMA.
+// fp32, ~200 VALU instructions per pixel-channel forward, ~100 backward; no MFMA (11-tap separable stencil).
 #include "fdgs_common.h"
 
 namespace fdgs
 {
-	constexpr int ST = 16;             // output tile edge
-	constexpr int SR = 5;              // window radius (11 taps)
-	constexpr int SH = ST + 2 * SR;    // 26: tile + halo
+	constexpr int STX = 32, STY = 16;    // output tile
+	constexpr int SR = 5;                // window radius (11 taps)
+	constexpr int SW = STX + 2 * SR;     // 42: tile + halo, columns
+	constexpr int SHH = STY + 2 * SR;    // 26: rows
+	constexpr int SSTR = 44;             // LDS row stride of the input tile, in (x,y) pairs (16-byte aligned rows for b128 reads)
+	constexpr int HSTR = 36;             // LDS row stride of the horizontally filtered moments
+	constexpr int STHREADS = 256;
+	typedef float v2f __attribute__((ext_vector_type(2)));
+	typedef float v4f __attribute__((ext_vector_type(4)));
 
 	// gaussian(11, 1.5) normalised, as utils/loss_utils.py:23-25
 	__device__ constexpr float GW[11] = {
 		0.0010283801f, 0.0075987582f, 0.0360007733f, 0.1093606874f, 0.2130055279f, 0.2660117149f,
 		0.2130055279f, 0.1093606874f, 0.0360007733f, 0.0075987582f, 0.0010283801f };
 
-	__global__ void __launch_bounds__(ST * ST) ssim_fwd_kernel(
+	__global__ void __launch_bounds__(STHREADS) ssim_fwd_kernel(
 		const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
 		float* __restrict__ dm_dmu1, float* __restrict__ dm_de11, float* __restrict__ dm_de12,
 		float* __restrict__ partial_l1, float* __restrict__ partial_ssim)
 	{
-		__shared__ float s1[SH][SH + 1];
-		__shared__ float s2[SH][SH + 1];
-		__shared__ float h[5][SH][ST + 1];   // horizontally filtered moments
-		__shared__ float red[2][ST * ST / WAVE];
+		__shared__ __attribute__((aligned(16))) v2f s_in[SHH][SSTR];   // (x, y)
+		__shared__ __attribute__((aligned(16))) v2f h_m[SHH][HSTR];     // horizontally filtered (x, y)
+		__shared__ __attribute__((aligned(16))) v2f h_s[SHH][HSTR];     // (x^2, y^2)
+		__shared__ __attribute__((aligned(16))) float h_x[SHH][HSTR];   // x y
+		__shared__ float red[2][STHREADS / WAVE];
 
 		const int c = blockIdx.z;
-		const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-		const int tid = threadIdx.y * ST + threadIdx.x;
+		const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
+		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		for (int i = tid; i < SH * SH; i += ST * ST)
+		for (int i = tid; i < SHH * SW; i += STHREADS)
 		{
-			const int ly = i / SH, lx = i % SH;
+			const int ly = i / SW, lx = i - ly * SW;
 			const int gy = y0 + ly - SR, gx = x0 + lx - SR;
 			const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
 			const size_t o = plane + (size_t)gy * W + gx;
-			s1[ly][lx] = in ? img1[o] : 0.0f;   // zero padding (F.conv2d padding = 5)
-			s2[ly][lx] = in ? img2[o] : 0.0f;
+			v2f p = { 0.0f, 0.0f };                    // zero padding (F.conv2d padding = 5)
+			if (in) { p.x = img1[o]; p.y = img2[o]; }
+			s_in[ly][lx] = p;
 		}
 		__syncthreads();
 
-		for (int i = tid; i < SH * ST; i += ST * ST)
+		// horizontal pass: thread -> (row, 4 adjacent columns)
+		if (tid < SHH * (STX / 4))
 		{
-			const int ly = i / ST, lx = i % ST;
-			float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+			const int ly = tid >> 3, cx = (tid & 7) * 4;
+			v2f p[16], sq[14];
+			float xy[14];
+			const v4f* src = reinterpret_cast<const v4f*>(&s_in[ly][cx]);
 #pragma unroll
-			for (int k = 0; k < 11; k++)
+			for (int i = 0; i < 7; i++) { const v4f q = src[i]; p[2 * i] = v2f{ q.x, q.y }; p[2 * i + 1] = v2f{ q.z, q.w }; }
+#pragma unroll
+			for (int i = 0; i < 14; i++) { sq[i] = p[i] * p[i]; xy[i] = p[i].x * p[i].y; }
+			v2f am[4], as[4];
+			float ax[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++)
 			{
-				const float w = GW[k], u = s1[ly][lx + k], v = s2[ly][lx + k];
-				a += w * u; b += w * v; aa += w * u * u; bb += w * v * v; ab += w * u * v;
+				am[j] = GW[0] * p[j]; as[j] = GW[0] * sq[j]; ax[j] = GW[0] * xy[j];
+#pragma unroll
+				for (int k = 1; k < 11; k++) { am[j] += GW[k] * p[j + k]; as[j] += GW[k] * sq[j + k]; ax[j] += GW[k] * xy[j + k]; }
 			}
-			h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+			v4f* dm = reinterpret_cast<v4f*>(&h_m[ly][cx]);
+			v4f* ds = reinterpret_cast<v4f*>(&h_s[ly][cx]);
+			dm[0] = v4f{ am[0].x, am[0].y, am[1].x, am[1].y }; dm[1] = v4f{ am[2].x, am[2].y, am[3].x, am[3].y };
+			ds[0] = v4f{ as[0].x, as[0].y, as[1].x, as[1].y }; ds[1] = v4f{ as[2].x, as[2].y, as[3].x, as[3].y };
+			*reinterpret_cast<v4f*>(&h_x[ly][cx]) = v4f{ ax[0], ax[1], ax[2], ax[3] };
 		}
 		__syncthreads();
 
-		const int lx = threadIdx.x, ly = threadIdx.y;
-		const int gx = x0 + lx, gy = y0 + ly;
+		// vertical pass: thread -> (column, 2 adjacent rows)
+		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * 2;
+		v2f vm[12], vs[12];
+		float vx[12];
+#pragma unroll
+		for (int r = 0; r < 12; r++) { vm[r] = h_m[ly0 + r][lx]; vs[r] = h_s[ly0 + r][lx]; vx[r] = h_x[ly0 + r][lx]; }
 		float l1 = 0.f, sv = 0.f;
-		if (gx < W && gy < H)
-		{
-			float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+		const int gx = x0 + lx;
 #pragma unroll
-			for (int k = 0; k < 11; k++)
+		for (int j = 0; j < 2; j++)
+		{
+			v2f mu = GW[0] * vm[j], e2 = GW[0] * vs[j];
+			float e12 = GW[0] * vx[j];
+#pragma unroll
+			for (int k = 1; k < 11; k++) { mu += GW[k] * vm[j + k]; e2 += GW[k] * vs[j + k]; e12 += GW[k] * vx[j + k]; }
+			const int gy = y0 + ly0 + j;
+			if (gx < W && gy < H)
 			{
-				const float w = GW[k];
-				mu1 += w * h[0][ly + k][lx]; mu2 += w * h[1][ly + k][lx];
-				e11 += w * h[2][ly + k][lx]; e22 += w * h[3][ly + k][lx]; e12 += w * h[4][ly + k][lx];
+				const float mu1 = mu.x, mu2 = mu.y, e11 = e2.x, e22 = e2.y;
+				const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+				const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+				const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
+				const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sg1 + sg2 + C2;
+				const float inv = 1.0f / (Cc * D);
+				const float m = A * B * inv;
+				// total derivative w.r.t. mu1 (through A, B, Cc, D), and w.r.t. the raw moments E[x^2], E[xy]
+				const float dm_dA = B * inv, dm_dB = A * inv, dm_dC = -m / Cc, dm_dD = -m / D;
+				const size_t o = plane + (size_t)gy * W + gx;
+				dm_dmu1[o] = dm_dA * 2.f * mu2 - dm_dB * 2.f * mu2 + dm_dC * 2.f * mu1 - dm_dD * 2.f * mu1;
+				dm_de11[o] = dm_dD;
+				dm_de12[o] = 2.f * dm_dB;
+				sv += m;
+				const v2f ctr = s_in[ly0 + j + SR][lx + SR];
+				l1 += fabsf(ctr.x - ctr.y);
 			}
-			const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-			const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-			const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
-			const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sg1 + sg2 + C2;
-			const float inv = 1.0f / (Cc * D);
-			const float m = A * B * inv;
-			// total derivative w.r.t. mu1 (through A, B, Cc, D), and w.r.t. the raw moments E[x^2], E[xy]
-			const float dm_dA = B * inv, dm_dB = A * inv, dm_dC = -m / Cc, dm_dD = -m / D;
-			const size_t o = plane + (size_t)gy * W + gx;
-			dm_dmu1[o] = dm_dA * 2.f * mu2 - dm_dB * 2.f * mu2 + dm_dC * 2.f * mu1 - dm_dD * 2.f * mu1;
-			dm_de11[o] = dm_dD;
-			dm_de12[o] = 2.f * dm_dB;
-			sv = m;
-			l1 = fabsf(s1[ly + SR][lx + SR] - s2[ly + SR][lx + SR]);
 		}
 		// per-tile partial sums (wave shuffle + 4 partials)
 #pragma unroll
@@ -107,60 +141,81 @@ namespace fdgs
 		}
 	}
 
-	__global__ void __launch_bounds__(ST * ST) ssim_bwd_kernel(
+	__global__ void __launch_bounds__(STHREADS) ssim_bwd_kernel(
 		const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
 		const float* __restrict__ dm_dmu1, const float* __restrict__ dm_de11, const float* __restrict__ dm_de12,
 		const float* __restrict__ upstream, float w_l1, float w_ssim, float* __restrict__ dL_dimg1)
 	{
-		__shared__ float s[3][SH][SH + 1];
-		__shared__ float h[3][SH][ST + 1];
+		__shared__ __attribute__((aligned(16))) v2f s_p[SHH][SSTR];    // (dm/dmu1, dm/dE11)
+		__shared__ __attribute__((aligned(16))) float s_q[SHH][SSTR];  // dm/dE12
+		__shared__ __attribute__((aligned(16))) v2f h_p[SHH][HSTR];
+		__shared__ __attribute__((aligned(16))) float h_q[SHH][HSTR];
 
 		const int c = blockIdx.z;
-		const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-		const int tid = threadIdx.y * ST + threadIdx.x;
+		const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
+		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		for (int i = tid; i < SH * SH; i += ST * ST)
+		for (int i = tid; i < SHH * SW; i += STHREADS)
 		{
-			const int ly = i / SH, lx = i % SH;
+			const int ly = i / SW, lx = i - ly * SW;
 			const int gy = y0 + ly - SR, gx = x0 + lx - SR;
 			const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
 			const size_t o = plane + (size_t)gy * W + gx;
-			s[0][ly][lx] = in ? dm_dmu1[o] : 0.0f;
-			s[1][ly][lx] = in ? dm_de11[o] : 0.0f;
-			s[2][ly][lx] = in ? dm_de12[o] : 0.0f;
+			v2f p = { 0.0f, 0.0f };
+			float q = 0.0f;
+			if (in) { p.x = dm_dmu1[o]; p.y = dm_de11[o]; q = dm_de12[o]; }
+			s_p[ly][lx] = p; s_q[ly][lx] = q;
 		}
 		__syncthreads();
-		for (int i = tid; i < SH * ST; i += ST * ST)
+		if (tid < SHH * (STX / 4))
 		{
-			const int ly = i / ST, lx = i % ST;
-			float a = 0.f, b = 0.f, d = 0.f;
+			const int ly = tid >> 3, cx = (tid & 7) * 4;
+			v2f p[16];
+			float q[16];
+			const v4f* sp = reinterpret_cast<const v4f*>(&s_p[ly][cx]);
+			const v4f* sq = reinterpret_cast<const v4f*>(&s_q[ly][cx]);
 #pragma unroll
-			for (int k = 0; k < 11; k++)
+			for (int i = 0; i < 7; i++) { const v4f t = sp[i]; p[2 * i] = v2f{ t.x, t.y }; p[2 * i + 1] = v2f{ t.z, t.w }; }
+#pragma unroll
+			for (int i = 0; i < 4; i++) { const v4f t = sq[i]; q[4 * i] = t.x; q[4 * i + 1] = t.y; q[4 * i + 2] = t.z; q[4 * i + 3] = t.w; }
+			v2f ap[4];
+			float aq[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++)
 			{
-				const float w = GW[k];
-				a += w * s[0][ly][lx + k]; b += w * s[1][ly][lx + k]; d += w * s[2][ly][lx + k];
+				ap[j] = GW[0] * p[j]; aq[j] = GW[0] * q[j];
+#pragma unroll
+				for (int k = 1; k < 11; k++) { ap[j] += GW[k] * p[j + k]; aq[j] += GW[k] * q[j + k]; }
 			}
-			h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = d;
+			v4f* dp = reinterpret_cast<v4f*>(&h_p[ly][cx]);
+			dp[0] = v4f{ ap[0].x, ap[0].y, ap[1].x, ap[1].y }; dp[1] = v4f{ ap[2].x, ap[2].y, ap[3].x, ap[3].y };
+			*reinterpret_cast<v4f*>(&h_q[ly][cx]) = v4f{ aq[0], aq[1], aq[2], aq[3] };
 		}
 		__syncthreads();
-		const int lx = threadIdx.x, ly = threadIdx.y;
-		const int gx = x0 + lx, gy = y0 + ly;
-		if (gx < W && gy < H)
-		{
-			float a = 0.f, b = 0.f, d = 0.f;
+		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * 2;
+		v2f vp[12];
+		float vq[12];
 #pragma unroll
-			for (int k = 0; k < 11; k++)
+		for (int r = 0; r < 12; r++) { vp[r] = h_p[ly0 + r][lx]; vq[r] = h_q[ly0 + r][lx]; }
+		const int gx = x0 + lx;
+		const float up = upstream[0];
+#pragma unroll
+		for (int j = 0; j < 2; j++)
+		{
+			v2f ab = GW[0] * vp[j];
+			float d = GW[0] * vq[j];
+#pragma unroll
+			for (int k = 1; k < 11; k++) { ab += GW[k] * vp[j + k]; d += GW[k] * vq[j + k]; }
+			const int gy = y0 + ly0 + j;
+			if (gx < W && gy < H)
 			{
-				const float w = GW[k];
-				a += w * h[0][ly + k][lx]; b += w * h[1][ly + k][lx]; d += w * h[2][ly + k][lx];
+				const size_t o = plane + (size_t)gy * W + gx;
+				const float x = img1[o], y = img2[o];
+				const float diff = x - y;
+				const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+				dL_dimg1[o] = up * (w_l1 * sgn + w_ssim * (ab.x + 2.f * x * ab.y + y * d));
 			}
-			const size_t o = plane + (size_t)gy * W + gx;
-			const float x = img1[o], y = img2[o];
-			const float up = upstream[0];
-			const float diff = x - y;
-			const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-			dL_dimg1[o] = up * (w_l1 * sgn + w_ssim * (a + 2.f * x * b + y * d));
 		}
 	}
 }
@@ -171,7 +226,7 @@ extern "C" int fdgs_l1_ssim_forward(const float* img, const float* gt, int32_t C
 {
 	using namespace fdgs;
 	if (!img || !gt || !dm_dmu1 || !dm_de11 || !dm_de12 || !partial_l1 || !partial_ssim || C <= 0 || H <= 0 || W <= 0) return FDGS_ERR_INVALID_ARG;
-	const dim3 grid(div_up(W, ST), div_up(H, ST), C), block(ST, ST, 1);
+	const dim3 grid(div_up(W, STX), div_up(H, STY), C), block(STHREADS, 1, 1);
 	hipLaunchKernelGGL(ssim_fwd_kernel, grid, block, 0, (hipStream_t)stream, img, gt, H, W, dm_dmu1, dm_de11, dm_de12, partial_l1, partial_ssim);
 	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
 }
@@ -184,13 +239,49 @@ extern "C" int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t 
 	if (!img || !gt || !dm_dmu1 || !dm_de11 || !dm_de12 || !upstream || !dL_dimg || C <= 0 || H <= 0 || W <= 0) return FDGS_ERR_INVALID_ARG;
 	const float n = (float)C * (float)H * (float)W;
 	const float w_l1 = (1.0f - lambda_dssim) / n, w_ssim = -lambda_dssim / n;
-	const dim3 grid(div_up(W, ST), div_up(H, ST), C), block(ST, ST, 1);
+	const dim3 grid(div_up(W, STX), div_up(H, STY), C), block(STHREADS, 1, 1);
 	hipLaunchKernelGGL(ssim_bwd_kernel, grid, block, 0, (hipStream_t)stream, img, gt, H, W, dm_dmu1, dm_de11, dm_de12, upstream, w_l1, w_ssim, dL_dimg);
+	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
+}
+
+namespace fdgs
+{
+	// loss = (1 - lambda) * sum(l1) / n + lambda * (1 - sum(ssim) / n), fixed summation order (deterministic)
+	__global__ void __launch_bounds__(256) l1_ssim_finish_kernel(const float* __restrict__ partial_l1, const float* __restrict__ partial_ssim,
+	                                                             int nparts, float inv_n, float lambda_dssim, float* __restrict__ out)
+	{
+		__shared__ float r0[256], r1[256];
+		float a = 0.f, b = 0.f;
+		for (int i = threadIdx.x; i < nparts; i += 256) { a += partial_l1[i]; b += partial_ssim[i]; }
+		r0[threadIdx.x] = a; r1[threadIdx.x] = b;
+		__syncthreads();
+		for (int o = 128; o > 0; o >>= 1)
+		{
+			if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+			__syncthreads();
+		}
+		if (threadIdx.x == 0)
+		{
+			const float l1 = r0[0] * inv_n, ss = r1[0] * inv_n;
+			out[0] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ss);
+			out[1] = l1;
+			out[2] = ss;
+		}
+	}
+}
+
+extern "C" int fdgs_l1_ssim_loss(const float* partial_l1, const float* partial_ssim, int32_t num_partials, int32_t C, int32_t H, int32_t W,
+                                 float lambda_dssim, float* loss_l1_ssim, void* stream)
+{
+	using namespace fdgs;
+	if (!partial_l1 || !partial_ssim || !loss_l1_ssim || num_partials <= 0 || C <= 0 || H <= 0 || W <= 0) return FDGS_ERR_INVALID_ARG;
+	const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
+	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial_l1, partial_ssim, num_partials, inv_n, lambda_dssim, loss_l1_ssim);
 	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
 }
 
 extern "C" int fdgs_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W)
 {
 	using namespace fdgs;
-	return div_up(W, ST) * div_up(H, ST) * C;
+	return div_up(W, STX) * div_up(H, STY) * C;
 }

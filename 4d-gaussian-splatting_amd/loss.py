@@ -26,12 +26,15 @@ class _FusedL1SSIM(torch.autograd.Function):
             rc = _capi.lib.fdgs_l1_ssim_forward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
                                                 d3.data_ptr(), parts[0].data_ptr(), parts[1].data_ptr(),
                                                 _capi.current_stream_handle(dev))
-        _capi._check(rc, "fdgs_l1_ssim_forward")
-        sums = parts.sum(dim=1) / float(C * H * W)
+            _capi._check(rc, "fdgs_l1_ssim_forward")
+            out = torch.empty(3, dtype=torch.float32, device=dev)
+            rc = _capi.lib.fdgs_l1_ssim_loss(parts[0].data_ptr(), parts[1].data_ptr(), nparts, C, H, W, float(lambda_dssim),
+                                             out.data_ptr(), _capi.current_stream_handle(dev))
+        _capi._check(rc, "fdgs_l1_ssim_loss")
         ctx.save_for_backward(img_c, gt_c, d1, d2, d3)
         ctx.lambda_dssim = float(lambda_dssim)
         ctx.shape = img.shape
-        return (1.0 - lambda_dssim) * sums[0] + lambda_dssim * (1.0 - sums[1])
+        return out[0]
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -72,5 +75,8 @@ def l1_ssim_value_and_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: 
         rc = _capi.lib.fdgs_l1_ssim_backward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
                                              d3.data_ptr(), upstream.data_ptr(), float(lambda_dssim), g.data_ptr(), st)
         _capi._check(rc, "fdgs_l1_ssim_backward")
-    sums = parts.sum(dim=1) / float(C * H * W)
-    return (1.0 - lambda_dssim) * sums[0] + lambda_dssim * (1.0 - sums[1]), g
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        rc = _capi.lib.fdgs_l1_ssim_loss(parts[0].data_ptr(), parts[1].data_ptr(), nparts, C, H, W, float(lambda_dssim),
+                                         out.data_ptr(), st)
+        _capi._check(rc, "fdgs_l1_ssim_loss")
+    return out[0], g

@@ -233,6 +233,10 @@ int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t 
                           const float* dm_dmu1, const float* dm_de11, const float* dm_de12,
                           const float* upstream, float lambda_dssim, float* dL_dimg, void* stream);
 int fdgs_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W);
+/* Reduces the per-tile partial sums of the forward call (fixed order: deterministic) to
+ * loss_l1_ssim[0] = (1 - lambda) * L1 + lambda * (1 - SSIM), [1] = L1, [2] = SSIM   (device memory, 3 floats). */
+int fdgs_l1_ssim_loss(const float* partial_l1, const float* partial_ssim, int32_t num_partials, int32_t C, int32_t H, int32_t W,
+                      float lambda_dssim, float* loss_l1_ssim, void* stream);
 
 /* ---- adjacent row: fused Adam over a flat parameter bucket ---------
  * torch.optim.Adam arithmetic (no amsgrad / weight decay) in one streaming pass over four flat fp32
