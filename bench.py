@@ -234,6 +234,10 @@ def main():
     n_fwd = args.steps * B
 
     def forward_only(c):
+        if use_pipeline:  # the same explicit call the step pipeline makes (no autograd bookkeeping)
+            from fdgs.fused import raw_forward, raw_settings
+            rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
+            return raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv)
         return render(c, model, pipe, bg) if args.reference_host else render_raw(c, model, pipe, bg)
 
     with torch.no_grad():

@@ -8,9 +8,10 @@ OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $REPO/bench.py --steps 25 --warmup 5 --cpu-samples 0 > $OUT/bench_under_rocprof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python $REPO/tools/quick_time.py C3 5 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python $REPO/tools/quick_time.py C3 5 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python $REPO/tools/quick_time.py C3 5 colour > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python $REPO/tools/quick_time.py C3 5 colour > $OUT/pmc_write.log 2>&1
 cd $REPO
+FDGS_PMC_CMD="python $REPO/tools/quick_time.py C3 3 colour" bash tools/pmc_sq.sh > $OUT/pmc_sq_$TAG.txt 2>&1
 python tools/pmc_traffic.py $OUT/stats $OUT/fetch $OUT/write $OUT/pmc_traffic_$TAG
 tail -1 $OUT/bench_under_rocprof.log | cut -c1-600
 # keep only the summaries (raw traces are large)

@@ -9,6 +9,7 @@ from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+colour_only = len(sys.argv) > 3 and sys.argv[3] == "colour"  # depth / alpha / flow without upstream gradient (the training case)
 dev = torch.device("cuda:0")
 sc = scene_to_device(synth.make_scene(synth.CONFIGS[name], seed=0), dev)
 g = {k: v.to(dev) for k, v in synth.make_upstream_grads(sc["W"], sc["H"], seed=1, scale=1e-2).items()}
@@ -20,8 +21,8 @@ def bwd(res):
     (R, color, flow, depth, T, radii, geom, binb, img, covs_com, om) = res
     return _C.rasterize_gaussians_backward(sc["bg"], sc["means3D"], om, radii, gg("colors_precomp"), gg("flow_2d"), sc["opacities"],
         gg("ts"), gg("scales"), gg("scales_t"), gg("rotations"), gg("rotations_r"), 1.0, gg("cov3D_precomp"), -1.0,
-        sc["world_view_transform"], sc["full_proj_transform"], sc["tanfovx"], sc["tanfovy"], g["grad_color"], g["grad_depth"],
-        g["grad_alpha"], g["grad_flow"], gg("shs"), sc["sh_degree"], sc["sh_degree_t"], sc["camera_center"], sc["timestamp"],
+        sc["world_view_transform"], sc["full_proj_transform"], sc["tanfovx"], sc["tanfovy"], g["grad_color"], None if colour_only else g["grad_depth"],
+        None if colour_only else g["grad_alpha"], None if colour_only else g["grad_flow"], gg("shs"), sc["sh_degree"], sc["sh_degree_t"], sc["camera_center"], sc["timestamp"],
         sc["time_duration"], sc["rot_4d"], sc["gaussian_dim"], sc["force_sh_3d"], geom, R, binb, img, False)
 for _ in range(3):
     r = fwd(); bwd(r)
