@@ -49,6 +49,14 @@ class _Scratch:
         t = self.buf.get(which)
         return t if t is not None else torch.empty(0, dtype=torch.uint8, device=self.device)
 
+    def release(self):
+        """The three buffers; breaks the self -> ctypes callback -> bound method -> self cycle, which would otherwise
+        keep ~0.5 GB per call alive until Python's cyclic GC runs (and make the caching allocator grow)."""
+        out = (self.get(_capi.FDGS_BUF_GEOMETRY), self.get(_capi.FDGS_BUF_BINNING), self.get(_capi.FDGS_BUF_IMAGE))
+        self.callback = None
+        self.buf = {}
+        return out
+
 
 class _NativeRasterizer:
     """Stand-in for the reference's pybind module ``_C`` (ext.cpp:15-19)."""
@@ -115,11 +123,10 @@ class _NativeRasterizer:
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), scratch.callback, None,
                                                   _capi.current_stream_handle(dev), C.byref(R))
+        geom, binb, img = scratch.release()
         _capi._check(rc, "fdgs_rasterize_forward")
         del keep
-        return (int(R.value), out_color, out_flow, out_depth, out_T, radii,
-                scratch.get(_capi.FDGS_BUF_GEOMETRY), scratch.get(_capi.FDGS_BUF_BINNING),
-                scratch.get(_capi.FDGS_BUF_IMAGE), covs_com, out_means3D)
+        return (int(R.value), out_color, out_flow, out_depth, out_T, radii, geom, binb, img, covs_com, out_means3D)
 
     def rasterize_gaussians_backward(self, bg, means3D, out_means3D, radii, colors, flows_2d, opacities, ts, scales,
                                      scales_t, rotations, rotations_r, scale_modifier, cov3D_precomp, prefilter_var,

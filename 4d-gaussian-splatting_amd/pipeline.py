@@ -42,7 +42,8 @@ class StepPipeline:
 
     def step(self, cams: Sequence, gts: Sequence[torch.Tensor], pipe, bg: torch.Tensor, scaling_modifier: float = 1.0):
         """Runs forward + loss + backward of every view, the gradient all-reduce and the optimizer step.
-        Returns (list of per-view results dict(render, radii, depth, alpha, flow, viewspace_grad), list of losses)."""
+        Returns (list of per-view results dict(render, radii, depth, alpha_T, flow, viewspace_grad, num_rendered), list
+        of losses); the tensors may be used on the caller's stream until the next call of step()."""
         B = len(cams)
         main = torch.cuda.current_stream(self.dev)
         self.sF.wait_stream(main)
@@ -76,11 +77,8 @@ class StepPipeline:
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)
         self.sF.wait_stream(self.sB)
-        for r in results:  # handed to the caller, who works on `main`
-            for t in r.values():
-                if torch.is_tensor(t):
-                    t.record_stream(main)
-        for l in losses:
-            l.record_stream(main)
+        # The returned tensors live in the F / B streams' allocator pools.  `main` has waited for both streams, and the
+        # next step() makes both streams wait for `main` first, so they are safe to read on `main` until then
+        # (no record_stream: it would defer every free by an event query and grow the pools).
         del keep
         return results, losses
