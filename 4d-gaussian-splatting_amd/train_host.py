@@ -137,6 +137,19 @@ class FlatAdam:
                 seg[:, :s["head"]] = s["lr_head"]
         return lr
 
+    def set_lr(self, name: str, lr: float, lr_head: float = None):
+        """Learning rate of one parameter tensor (the reference's ``param_group['lr'] = lr``, gaussian_model.py:359-365)."""
+        b, e = self.model.offsets[name]
+        for i, s in enumerate(self.segments):
+            if s["begin"] == b and s["end"] == e:
+                s["lr"] = float(lr)
+                s["lr_head"] = float(lr if lr_head is None else lr_head)
+                if self._native is not None:
+                    self._native[i].lr, self._native[i].lr_head = s["lr"], s["lr_head"]
+                self._lr_vec = None
+                return
+        raise KeyError(name)
+
     @torch.no_grad()
     def step(self):
         self.step_count += 1

@@ -72,3 +72,48 @@ def test_flat_bucket_allreduce_world2():
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res[0] == res[1]
+
+
+def _stats_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fdgs import harness
+    P, B = 300, 2
+    # every rank can generate everybody's views (seeded): the union is what a single process with batch B*world would see
+    def views(step, r):
+        g = torch.Generator().manual_seed(1000 * step + r)
+        return [{"radii": torch.randint(-3, 7, (P,), generator=g).clamp(min=0).to(torch.int32),
+                 "viewspace_grad": torch.randn(P, 3, generator=g)} for _ in range(B)]
+    st = harness.DensificationStats(P, "cpu", world)
+    single = harness.DensificationStats(P, "cpu", 1)
+    for step in range(3):
+        t_grad = torch.randn(P, 1, generator=torch.Generator().manual_seed(77 + step))  # the (already all-reduced) dL/dt
+        st.update(views(step, rank), t_grad, B * world)
+        single.update([v for r in range(world) for v in views(step, r)], t_grad, B * world)
+    for a, b in ((st.xyz_gradient_accum, single.xyz_gradient_accum), (st.t_gradient_accum, single.t_gradient_accum),
+                 (st.denom, single.denom), (st.max_radii2D, single.max_radii2D)):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+    # identical on every rank -> densification decisions derived from them need no broadcast
+    packed = torch.cat([st.xyz_gradient_accum.flatten(), st.t_gradient_accum.flatten(), st.denom.flatten(), st.max_radii2D])
+    both = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(both, packed)
+    assert torch.equal(both[0], both[1])
+    q.put((rank, float(packed.abs().sum())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_densification_stats_identical_on_all_ranks_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stats_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res[0] == res[1]
