@@ -112,10 +112,16 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
           batch_size: int = 4, world_size: int = 1, rank: int = 0, seed: int = 0, lambda_dssim: float = 0.2,
           position_lr_init: float = 1.6e-4, position_lr_final: float = 1.6e-6, position_lr_delay_mult: float = 0.01,
           position_lr_max_steps: int = 30000, sh_increase_interval: int = 1000, max_sh_degree: Optional[int] = None,
-          densify_until_iter: int = 15000, on_densify: Optional[Callable] = None, log_every: int = 0,
+          densify_until_iter: int = 15000, densify_from_iter: int = 500, densification_interval: int = 100,
+          opacity_reset_interval: int = 3000, densify_grad_threshold: float = 2e-4, densify_grad_t_threshold: float = 2e-4 / 40,
+          thresh_opa_prune: float = 0.005, percent_dense: float = 0.01, cameras_extent: Optional[float] = None,
+          densify_until_num_points: int = -1, on_densify: Optional[Callable] = None, log_every: int = 0,
           log: Callable[[str], None] = print) -> Dict[str, List[float]]:
     """The reference's training loop (train.py:82-254) over ``cameras`` / ``gts`` (all views, identical on every rank;
-    each rank renders its FrameShard slice).  Returns the logged history {"iteration", "loss", "psnr"}."""
+    each rank renders its FrameShard slice).  Returns the logged history {"iteration", "loss", "psnr"}.
+    Densification (train.py:229-244) runs when ``cameras_extent`` is given: every rank takes the same decisions from the
+    all-reduced statistics and draws the split samples from a generator seeded with (seed, iteration), so the replicas
+    stay identical without a broadcast.  ``on_densify(model, optimizer, stats, iteration)`` replaces that default."""
     shard = iter(FrameShard(len(cameras), batch_size, world_size, rank, seed))
     steppipe = StepPipeline(model, optimizer, world_size=world_size, lambda_dssim=lambda_dssim)
     stats = DensificationStats(model.P, model.flat.device, world_size)
@@ -130,9 +136,25 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
         results, losses = steppipe.step([cameras[i] for i in idx], [gts[i] for i in idx], pipe, bg)
         if iteration < densify_until_iter:                                              # train.py:229-244
             t_grad = model.params["_t"].grad if model.gaussian_dim == 4 else None      # already all-reduced (mean over the batch)
-            stats.update(results, t_grad, batch_size * world_size)
-            if on_densify is not None:
-                on_densify(model, optimizer, stats, iteration)
+            if densify_until_num_points < 0 or model.P < densify_until_num_points:
+                stats.update(results, t_grad, batch_size * world_size)
+                if on_densify is not None:
+                    on_densify(model, optimizer, stats, iteration)
+                    steppipe.sink = model.grad_sink()
+                elif cameras_extent is not None:
+                    if iteration > densify_from_iter and iteration % densification_interval == 0:        # train.py:238-240
+                        from .densify import densify_and_prune
+                        gen = torch.Generator(device=model.flat.device).manual_seed(seed * 1000003 + iteration)
+                        size_threshold = 20 if iteration > opacity_reset_interval else None
+                        rep = densify_and_prune(model, optimizer, stats, densify_grad_threshold, thresh_opa_prune, cameras_extent,
+                                                size_threshold, densify_grad_t_threshold, percent_dense=percent_dense, generator=gen)
+                        steppipe.sink = model.grad_sink()
+                        if rank == 0 and log_every:
+                            log("[it %5d] densify: %d -> %d Gaussians (%d cloned, %d split)" % (iteration, rep["P_old"], rep["P_new"],
+                                                                                              rep["cloned"], rep["split_parents"]))
+                    if iteration % opacity_reset_interval == 0:                                          # train.py:242-243
+                        from .densify import reset_opacity
+                        reset_opacity(model, optimizer)
         if log_every and (iteration % log_every == 0 or iteration == 1 or iteration == iterations):
             with torch.no_grad():
                 loss = float(torch.stack(losses).mean())

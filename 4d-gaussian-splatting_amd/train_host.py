@@ -50,24 +50,12 @@ class GaussianParams:
                 "_opacity": _inv_sigmoid(scene["opacities"].clamp(1e-6, 1 - 1e-6)), "_scaling": torch.log(scene["scales"]),
                 "_rotation": scene["rotations"], "_t": scene["ts"], "_scaling_t": torch.log(scene["scales_t"]),
                 "_rotation_r": scene["rotations_r"]}
-        sizes = {n: int(torch.tensor(shapes[n]).prod()) for n in self.NAMES}
-        total = sum(sizes.values())
-        self.flat = torch.empty(total, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.params: Dict[str, torch.Tensor] = {}
-        self.offsets: Dict[str, Tuple[int, int]] = {}
-        off = 0
-        for name in self.NAMES:
-            n = sizes[name]
-            view = self.flat[off:off + n].view(shapes[name])
-            view.copy_(init[name].to(device).reshape(shapes[name]))
-            p = view.requires_grad_(True)
-            p.grad = self.flat_grad[off:off + n].view(shapes[name])
-            self.params[name] = p
-            setattr(self, name, p)  # the reference's attribute names (scene/gaussian_model.py:70-80)
-            self.offsets[name] = (off, off + n)
-            off += n
-        self.P, self.M = P, M
+        self.M = M
+        total = P * self.floats_per_gaussian()
+        self._bind(torch.empty(total, dtype=torch.float32, device=device), torch.zeros(total, dtype=torch.float32, device=device), P)
+        with torch.no_grad():
+            for name in self.NAMES:
+                self.params[name].copy_(init[name].to(device).reshape(shapes[name]))
         self.active_sh_degree = int(scene["sh_degree"])
         self.active_sh_degree_t = int(scene["sh_degree_t"])
         self.time_duration = [0.0, float(scene["time_duration"])]
@@ -76,6 +64,32 @@ class GaussianParams:
         self.prefilter_var = -1.0
         self.env_map = None
         self.get_max_sh_channels = M
+
+    def row_floats(self) -> List[int]:
+        """floats per Gaussian of every segment of the flat bucket, in NAMES order"""
+        return [3, self.M * 3, 1, 3, 4, 1, 1, 4]
+
+    def floats_per_gaussian(self) -> int:
+        return sum(self.row_floats())
+
+    def _bind(self, flat: torch.Tensor, flat_grad: torch.Tensor, P: int):
+        """(Re)creates the parameter views over ``flat`` / ``flat_grad`` for P Gaussians (segments back to back)."""
+        shapes = {"_xyz": (P, 3), "_features": (P, self.M, 3), "_opacity": (P, 1), "_scaling": (P, 3), "_rotation": (P, 4),
+                  "_t": (P, 1), "_scaling_t": (P, 1), "_rotation_r": (P, 4)}
+        assert flat.numel() == flat_grad.numel() == P * self.floats_per_gaussian()
+        self.flat, self.flat_grad = flat, flat_grad
+        self.params = {}
+        self.offsets = {}
+        off = 0
+        for name, rf in zip(self.NAMES, self.row_floats()):
+            n = P * rf
+            p = self.flat[off:off + n].view(shapes[name]).requires_grad_(True)
+            p.grad = self.flat_grad[off:off + n].view(shapes[name])
+            self.params[name] = p
+            setattr(self, name, p)  # the reference's attribute names (scene/gaussian_model.py:70-80)
+            self.offsets[name] = (off, off + n)
+            off += n
+        self.P = P
 
     # ---- scene/gaussian_model.py:179-219 ----
     get_xyz = property(lambda s: s.params["_xyz"])
@@ -136,6 +150,17 @@ class FlatAdam:
                 seg = lr[s["begin"]:s["end"]].view(-1, s["period"])
                 seg[:, :s["head"]] = s["lr_head"]
         return lr
+
+    def rebind(self, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor):
+        """After the model was re-laid out (densification): new moment buffers, segment table for the new offsets;
+        the learning rates set so far are kept."""
+        old = self.segments
+        self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
+        self.segments = self.model.lr_segments()
+        for s_new, s_old in zip(self.segments, old):
+            s_new["lr"], s_new["lr_head"] = s_old["lr"], s_old["lr_head"]
+        self._native = None
+        self._lr_vec = None
 
     def set_lr(self, name: str, lr: float, lr_head: float = None):
         """Learning rate of one parameter tensor (the reference's ``param_group['lr'] = lr``, gaussian_model.py:359-365)."""

@@ -253,6 +253,32 @@ int fdgs_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                    const fdgs_adam_segment* segments, int32_t num_segments,
                    float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/* ---- adjacent row: densification / pruning of the flat-bucket model --------------
+ * Replaces the boolean-mask gathers and torch.cat calls of scene/gaussian_model.py:391-610 (densify_and_clone,
+ * densify_and_split, prune_points, cat_tensors_to_optimizer, _prune_optimizer) for a model whose parameters,
+ * exp_avg and exp_avg_sq are one flat buffer each (segments [P,row_0] [P,row_1] ... back to back). */
+#define FDGS_DENSIFY_CLONE 1        /* clone this Gaussian (gaussian_model.py:545-569)                          */
+#define FDGS_DENSIFY_SPLIT 2        /* replace it by N samples (:487-543)                                       */
+#define FDGS_DENSIFY_PRUNE 4        /* the Gaussian (and its clone) fails the final prune test (:598-603)       */
+#define FDGS_DENSIFY_PRUNE_CHILD 8  /* its split children (scaling / (0.8 N)) fail the final prune test         */
+/* Per-Gaussian decision flags from the densification statistics.  max_screen_size <= 0: no size test
+ * (`if max_screen_size:`); percent_dense, extent: as training_setup / cameras_extent; prune_only as in :584. */
+int fdgs_densify_classify(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,
+                          const float* opacity_raw, const float* max_radii2D, float max_grad, float min_opacity,
+                          float extent, float max_screen_size, float percent_dense, int32_t N, int32_t prune_only,
+                          uint8_t* flags, void* stream);
+/* Builds the three new flat buffers: row j of every segment is row src[j] of the old one; kind[j] == 0 keeps the
+ * Adam moments, anything else zeroes them (new points, gaussian_model.py:441-442). */
+int fdgs_densify_gather(int32_t num_segments, const int32_t* row_floats, int64_t P_old, int64_t P_new,
+                        const int32_t* src, const uint8_t* kind, const float* old_params, const float* old_exp_avg,
+                        const float* old_exp_avg_sq, float* new_params, float* new_exp_avg, float* new_exp_avg_sq, void* stream);
+/* Split children (gaussian_model.py:497-524): new_* point at the children's rows of the new arrays; parent[c] indexes
+ * the OLD arrays; samples [n,4] (rot_4d) or [n,3] (+ samples_t [n] for 4D without rot_4d) are draws of N(0, std). */
+int fdgs_densify_split(int32_t n_children, int32_t N, int32_t rot_4d, int32_t gaussian_dim, const int32_t* parent,
+                       const float* samples, const float* samples_t, const float* xyz, const float* t, const float* scaling,
+                       const float* scaling_t, const float* rotation, const float* rotation_r,
+                       float* new_xyz, float* new_t, float* new_scaling, float* new_scaling_t, void* stream);
+
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* fdgs_last_error(void);
 int fdgs_version(void);
