@@ -279,6 +279,12 @@ int fdgs_densify_split(int32_t n_children, int32_t N, int32_t rot_4d, int32_t ga
                        const float* scaling_t, const float* rotation, const float* rotation_r,
                        float* new_xyz, float* new_t, float* new_scaling, float* new_scaling_t, void* stream);
 
+/* ---- adjacent row: simple-knn's distCUDA2 (simple-knn/spatial.cu:15-27) ----------
+ * mean_dist2[i] = mean of the squared distances from points[i] to its three nearest other points ([P,3] float,
+ * device).  scratch: fdgs_knn_scratch_bytes(P) bytes of device memory.  Exact search; bit-exact vs the oracle. */
+size_t fdgs_knn_scratch_bytes(int32_t P);
+int fdgs_dist2_knn3(int32_t P, const float* points, float* mean_dist2, void* scratch, void* stream);
+
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* fdgs_last_error(void);
 int fdgs_version(void);
