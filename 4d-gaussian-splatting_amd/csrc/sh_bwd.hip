@@ -4,7 +4,7 @@
 // backward.cu:20-139, 144-481): every thread reads its own 12*M bytes of coefficients and writes its own
 // 12*M bytes of dL_dsh with a 12*M-byte stride between threads.  At M = 48 that is 576 B in and 576 B out per
 // Gaussian -- 80 % of all bytes the whole per-Gaussian backward moves -- so it gets its own kernel here:
-//   * a wave owns 64 consecutive Gaussians; their coefficient rows are staged block by block (16
+//   * a wave owns 32 consecutive Gaussians (64 measured 1 % slower: half the waves in flight); their rows are staged block by block (16
 //     coefficients = 192 B per Gaussian) through a wave-private LDS tile with fully coalesced dwordx4 loads;
 //   * each lane then walks ITS Gaussian's row in LDS (row stride 49 floats: conflict free), accumulates the
 //     direction / time dot products in registers and overwrites the row with dL_dsh;
@@ -25,6 +25,11 @@ namespace fdgs
 {
 	constexpr int SHB_STRIDE = 49;   // LDS row stride in floats (odd: lane-per-row access is conflict free)
 	constexpr int SHB_CH = 12;       // float4 chunks per Gaussian and block (16 coefficients x 3 / 4)
+#ifndef FDGS_SHB_GPW
+#define FDGS_SHB_GPW 32
+#endif
+	constexpr int SHB_GPW = FDGS_SHB_GPW;   // Gaussians per wave: 32 halves the LDS tile (6.3 KB) -> twice the waves per CU in flight
+	constexpr int SHB_IT = SHB_CH * SHB_GPW / WAVE;  // float4 per lane and block
 
 	struct ShBwdArgs
 	{
@@ -87,16 +92,16 @@ namespace fdgs
 	__device__ __forceinline__ void tile_load16(float* __restrict__ tile, const float* __restrict__ src, int g0, int P, size_t row_floats,
 	                                            int first_float, unsigned long long mask, int lane)
 	{
-		float4 v[SHB_CH];
+		float4 v[SHB_IT];
 #pragma unroll
-		for (int i = 0; i < SHB_CH; i++)
+		for (int i = 0; i < SHB_IT; i++)
 		{
 			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
 			const bool ok = g0 + g < P && ((mask >> g) & 1ull);
 			v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(g0 + g) * row_floats + first_float + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 #pragma unroll
-		for (int i = 0; i < SHB_CH; i++)
+		for (int i = 0; i < SHB_IT; i++)
 		{
 			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
 			float* d = tile + g * SHB_STRIDE + 4 * q;
@@ -107,7 +112,7 @@ namespace fdgs
 	                                             int first_float, unsigned long long mask, int lane, bool accum)
 	{
 #pragma unroll
-		for (int i = 0; i < SHB_CH; i++)
+		for (int i = 0; i < SHB_IT; i++)
 		{
 			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
 			if (g0 + g < P)
@@ -132,7 +137,7 @@ namespace fdgs
 	{
 		int g = lane / nf, pos = lane - g * nf;
 		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
-		for (int e = lane; e < WAVE * nf; e += WAVE)
+		for (int e = lane; e < SHB_GPW * nf; e += WAVE)
 		{
 			if (g0 + g < P && ((mask >> g) & 1ull)) tile[g * SHB_STRIDE + pos] = src[(size_t)(g0 + g) * row_floats + first_float + pos];
 			g += dg; pos += dpos;
@@ -144,7 +149,7 @@ namespace fdgs
 	{
 		int g = lane / nf, pos = lane - g * nf;
 		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
-		for (int e = lane; e < WAVE * nf; e += WAVE)
+		for (int e = lane; e < SHB_GPW * nf; e += WAVE)
 		{
 			if (g0 + g < P)
 			{
@@ -162,12 +167,12 @@ namespace fdgs
 	// operations of one wave execute in order) and waves of different phases (load / compute / store) overlap freely.
 	__global__ void __launch_bounds__(WAVE) sh_bwd_kernel(const ShBwdArgs a)
 	{
-		__shared__ float tile[WAVE * SHB_STRIDE];
+		__shared__ float tile[SHB_GPW * SHB_STRIDE];
 		const int lane = threadIdx.x;
-		float* row = tile + lane * SHB_STRIDE;
-		const int g0 = blockIdx.x * WAVE;
+		float* row = tile + (lane < SHB_GPW ? lane : 0) * SHB_STRIDE;
+		const int g0 = blockIdx.x * SHB_GPW;
 		const int tid_g = g0 + lane;
-		const bool valid = tid_g < a.P;
+		const bool valid = lane < SHB_GPW && tid_g < a.P;
 		const int idx = valid ? tid_g : a.P - 1;
 		const bool visible = valid && a.radii[idx] > 0; // backward.cu:873
 		const size_t row_floats = (size_t)3 * a.M;
@@ -286,7 +291,7 @@ namespace fdgs
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
-		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, WAVE)), dim3(WAVE), 0, stream, a);
+		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, SHB_GPW)), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
 	}
 }

@@ -146,6 +146,29 @@ def pmc_traffic(stage):
         return None
 
 
+def pmc_valu(stage):
+    """VALU issue statistics of the dominant kernel from the committed SQ-counter pass (tools/pmc_sq.sh), or None."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_sq_r*.txt")))
+    if not files:
+        return None
+    try:
+        cur, vals = None, {}
+        for line in open(files[-1]):
+            t = line.split()
+            if not line.startswith(" ") and t:
+                cur = line.strip()
+            elif cur and stage in cur and len(t) >= 2 and t[0].startswith("SQ_"):
+                vals[t[0]] = float(t[1])
+        if "SQ_ACTIVE_INST_VALU" not in vals:
+            return None
+        simds = 256 * 4
+        return {"insts_valu_per_launch": int(vals.get("SQ_INSTS_VALU", 0)),
+                "valu_issue_cycles_per_simd": int(vals["SQ_ACTIVE_INST_VALU"] * 4 / simds),
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     world, rank, local = init_dist(args)
@@ -274,7 +297,13 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
                 "avg_kernel_ms": stages[dom]["ms"], "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
-                "note": "blend kernels are VALU/atomic-bound (SURVEY.md 8d): frac of HBM peak is reported as the contract asks"}
+                "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
+                        "peak is reported as the contract asks; 'valu' gives the issue cycles per SIMD from the SQ counters, "
+                        "to compare with avg_kernel_ms x the shader clock (2.4 GHz max)"}
+    valu = pmc_valu(dom)
+    if valu:
+        valu["kernel_cycles_at_2.4GHz"] = int(stages[dom]["ms"] * 1e-3 * 2.4e9)
+        roofline["valu"] = valu
     out = {
         "metric": "train-step images/sec + forward Mpix/s, 300k 4D Gaussians @1352x1014",
         "value": round(world * B * args.steps / dt, 3),
