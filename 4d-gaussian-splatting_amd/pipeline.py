@@ -19,7 +19,7 @@ import torch
 
 from .fused import raw_backward, raw_forward, raw_settings
 from .loss import l1_ssim_value_and_grad
-from .train_host import allreduce_gradients
+from .train_host import allreduce_and_step
 
 
 class StepPipeline:
@@ -72,8 +72,8 @@ class StepPipeline:
                             "viewspace_grad": grads[0], "num_rendered": R})
             losses.append(loss)
         with torch.cuda.stream(self.sB):
-            allreduce_gradients(m, self.world, average=False)  # the losses were scaled by 1 / (B * world)
-            self.opt.step()
+            # the losses were scaled by 1 / (B * world): SUM = mean; Adam on chunk k overlaps the all-reduce of chunk k+1
+            allreduce_and_step(m, self.opt, self.world, chunks=4, average=False)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)
         self.sF.wait_stream(self.sB)

@@ -178,30 +178,40 @@ class FlatAdam:
     @torch.no_grad()
     def step(self):
         self.step_count += 1
+        self.step_range(0, self.model.flat.numel())
+
+    @torch.no_grad()
+    def step_range(self, begin: int, end: int):
+        """Adam update of flat[begin:end] for the CURRENT step_count (``step()`` = increment + whole range).  Used to
+        update one chunk of the bucket while the all-reduce of the next chunk is still in flight."""
         m = self.model
+        n = end - begin
+        if n <= 0:
+            return
         if m.flat.is_cuda:
             from . import _capi
-            if self._native is None:
-                arr = (_capi.FdgsAdamSegment * len(self.segments))()
-                for i, s in enumerate(self.segments):
-                    arr[i] = _capi.FdgsAdamSegment(s["begin"], s["end"], s["lr"], s["lr_head"], s["period"], s["head"])
-                self._native = arr
+            # segment table relative to `begin` (a segment that starts before the chunk keeps its phase: negative begin)
+            arr = (_capi.FdgsAdamSegment * len(self.segments))()
+            for i, s in enumerate(self.segments):
+                arr[i] = _capi.FdgsAdamSegment(s["begin"] - begin, s["end"] - begin, s["lr"], s["lr_head"], s["period"], s["head"])
+            self._native = arr
             with torch.cuda.device(m.flat.device):
-                rc = _capi.lib.fdgs_adam_step(m.flat.data_ptr(), m.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                                              self.exp_avg_sq.data_ptr(), m.flat.numel(), self._native,
-                                              len(self.segments), self.betas[0], self.betas[1], self.eps,
+                rc = _capi.lib.fdgs_adam_step(m.flat.data_ptr() + 4 * begin, m.flat_grad.data_ptr() + 4 * begin,
+                                              self.exp_avg.data_ptr() + 4 * begin, self.exp_avg_sq.data_ptr() + 4 * begin, n,
+                                              arr, len(self.segments), self.betas[0], self.betas[1], self.eps,
                                               self.step_count, _capi.current_stream_handle(m.flat.device))
             _capi._check(rc, "fdgs_adam_step")
             return
         if self._lr_vec is None:
             self._lr_vec = self.lr_vector()
         b1, b2 = self.betas
-        g = m.flat_grad
-        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
-        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        sl = slice(begin, end)
+        g = m.flat_grad[sl]
+        self.exp_avg[sl].mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq[sl].mul_(b2).addcmul_(g, g, value=1 - b2)
         bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
-        denom = self.exp_avg_sq.sqrt().div_(math.sqrt(bc2)).add_(self.eps)
-        m.flat.sub_(self._lr_vec / bc1 * (self.exp_avg / denom))
+        denom = self.exp_avg_sq[sl].sqrt().div_(math.sqrt(bc2)).add_(self.eps)
+        m.flat[sl].sub_(self._lr_vec[sl] / bc1 * (self.exp_avg[sl] / denom))
 
 
 def make_optimizer(model: GaussianParams) -> FlatAdam:
@@ -217,6 +227,28 @@ def allreduce_gradients(model: GaussianParams, world_size: int, average: bool = 
         dist.all_reduce(model.flat_grad, op=dist.ReduceOp.SUM)
         if average:
             model.flat_grad.mul_(1.0 / world_size)
+
+
+def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: int, chunks: int = 4, average: bool = False) -> None:
+    """Gradient all-reduce + Adam with the two overlapped: the bucket is cut into ``chunks`` pieces, all all-reduces
+    are issued at once (they run back to back on the collective stream) and chunk k is updated as soon as ITS
+    all-reduce has finished, while chunk k+1 is still on the wire.  Same result as allreduce_gradients + step()."""
+    if world_size <= 1:
+        optimizer.step()
+        return
+    import torch.distributed as dist
+    n = model.flat.numel()
+    chunks = max(1, min(int(chunks), n))
+    step = -(-n // chunks)
+    step += (-step) % 4                      # 16-byte aligned pieces (the Adam kernel's float4 path)
+    bounds = [(b, min(b + step, n)) for b in range(0, n, step)]
+    works = [dist.all_reduce(model.flat_grad[b:e], op=dist.ReduceOp.SUM, async_op=True) for b, e in bounds]
+    optimizer.step_count += 1
+    for w, (b, e) in zip(works, bounds):
+        w.wait()
+        if average:
+            model.flat_grad[b:e].mul_(1.0 / world_size)
+        optimizer.step_range(b, e)
 
 
 # ------------------------- utils/loss_utils.py:17-64 -------------------------

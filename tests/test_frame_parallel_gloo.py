@@ -50,7 +50,18 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, local)
         expect = sum(gathered) / world
         assert torch.allclose(model.flat_grad, expect, rtol=0, atol=1e-6)
-        opt.step()
+        if step == 1:
+            # chunked path: all-reduce + Adam per chunk (allreduce_and_step) == all-reduce, then one Adam step
+            twin = train_host.GaussianParams(scene, torch.device("cpu"))
+            twin_opt = train_host.make_optimizer(twin)
+            with torch.no_grad():
+                twin.flat.copy_(model.flat); twin.flat_grad.copy_(local)
+            twin_opt.exp_avg.copy_(opt.exp_avg); twin_opt.exp_avg_sq.copy_(opt.exp_avg_sq); twin_opt.step_count = opt.step_count
+            train_host.allreduce_and_step(twin, twin_opt, world, chunks=5, average=True)
+            opt.step()
+            assert torch.equal(twin.flat, model.flat) and torch.equal(twin_opt.exp_avg_sq, opt.exp_avg_sq)
+        else:
+            opt.step()
         flats = [torch.zeros_like(model.flat) for _ in range(world)]
         dist.all_gather(flats, model.flat.detach())
         assert torch.equal(flats[0], flats[1]), "replicas diverged"

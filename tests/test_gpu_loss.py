@@ -70,3 +70,26 @@ def test_fused_adam_matches_torch_adam(gpu_device):
         ref[idx] = q.detach()
     assert (out - ref).abs().max().item() <= 1e-6
     assert (out - init).abs().max().item() > 1e-4  # it did move
+
+
+def test_adam_step_range_equals_whole_step(gpu_device):
+    """FlatAdam.step_range over pieces of the bucket (segment table shifted, phases kept: negative begins) updates
+    exactly like one step over the whole bucket -- what allreduce_and_step relies on."""
+    from fdgs import synth, train_host
+    cfg = synth.SceneConfig("ad", 777, 64, 48, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=1)
+    a = train_host.GaussianParams(scene, gpu_device)
+    b = train_host.GaussianParams(scene, gpu_device)
+    oa, ob = train_host.make_optimizer(a), train_host.make_optimizer(b)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for _ in range(3):
+        grad = torch.randn(a.flat.shape, generator=g).to(gpu_device) * 1e-3
+        a.flat_grad.copy_(grad); b.flat_grad.copy_(grad)
+        oa.step()
+        ob.step_count += 1
+        n = b.flat.numel()
+        cuts = [0, 1000, 1000 + 4 * 12345, n // 2 // 4 * 4, n]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ob.step_range(lo, hi)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat, b.flat) and torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
