@@ -106,3 +106,16 @@ def test_colour_only_backward_vs_oracle(name, gpu_device):
     _, hipg = run_hip(scene, gpu_device, nones)
     _, refg = run_oracle(scene, zeros, kind="port")
     check_backward(hipg, refg, name + " colour-only")
+
+
+def test_depth_only_backward_vs_oracle(gpu_device):
+    """No upstream gradient for the colour image (NULL at the C ABI), only for depth and alpha: the general backward
+    variant with zeros substituted in the kernel equals the oracle fed with an explicit zero colour gradient."""
+    name = "rot4d_sh3_t1"
+    scene = _scene(name)
+    grads = synth.make_upstream_grads(scene["W"], scene["H"], seed=4, scale=GRAD_SCALE)
+    zeros = {k: (torch.zeros_like(v) if k in ("grad_color", "grad_flow") else v) for k, v in grads.items()}
+    nones = {k: (None if k in ("grad_color", "grad_flow") else v) for k, v in grads.items()}
+    _, hipg = run_hip(scene, gpu_device, nones)
+    _, refg = run_oracle(scene, zeros, kind="port")
+    check_backward(hipg, refg, name + " depth+alpha only")
