@@ -35,7 +35,8 @@ namespace fdgs
 		int rot_4d, gaussian_dim, force_sh_3d, raw, accum;
 		const int32_t* radii; const float* means; /* out_means3D */
 		const float* cov3D; const uint8_t* clamped;
-		const float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
+		float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
+		int rezero; /* leave the record zero for the next backward (fdgs_backward_out.grad_accum_clean) */
 		float *dL_dmean2D, *dL_dcolor, *dL_dflows;
 		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
 	};
@@ -72,8 +73,9 @@ namespace fdgs
 		float4 drot = make_float4(0, 0, 0, 0), drot_r = make_float4(0, 0, 0, 0);
 		// unpack the accumulator record (blend_bwd.hip): colour 0-2, depth 3, flow 4-5, mean2D x,y 6-7,
 		// conic xx 8, yy 9, xy 10, opacity 11, SH-backward mean/time 12-15
-		const float4* rec = reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS);
+		float4* rec = reinterpret_cast<float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS);
 		const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+		if (a.rezero) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z; }
 		const float3 g_color = make_float3(r0.x, r0.y, r0.z);
 		const float2 g_flow = make_float2(r1.x, r1.y);
 		const float3 g_mean2D = make_float3(r1.z, r1.w, r0.w);
@@ -355,7 +357,7 @@ namespace fdgs
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.cov3D = reinterpret_cast<const float*>(geom + L.cov3D);
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
-		a.gacc = out.grad_accum;
+		a.gacc = out.grad_accum; a.rezero = out.grad_accum_clean;
 		a.dL_dmean2D = out.dL_dmeans2D; a.dL_dcolor = out.dL_dcolors; a.dL_dflows = out.dL_dflows;
 		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
 		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;

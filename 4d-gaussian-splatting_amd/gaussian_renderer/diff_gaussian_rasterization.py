@@ -133,12 +133,14 @@ class _NativeRasterizer:
                                      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
-                                     imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False):
+                                     imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False, grad_accum=None):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
         preallocated contiguous tensors the kernels write into (e.g. views of a flat gradient bucket);
-        ``accumulate``: the kernels ADD into those parameter gradients instead of overwriting them."""
+        ``accumulate``: the kernels ADD into those parameter gradients instead of overwriting them;
+        ``grad_accum``: a persistent all-zero [P,16] float32 scratch tensor owned by the caller -- the call then skips
+        its memset and leaves the tensor all zero again (fdgs_backward_out.grad_accum_clean)."""
         dev = means3D.device
         # The reference always receives four dense tensors (autograd materialises zeros).  Here an image gradient may
         # be None = "no upstream gradient": the kernels then skip that term (colour-only backward when only
@@ -161,7 +163,7 @@ class _NativeRasterizer:
             "dL_dflows": torch.empty((P, 2), **fo), "dL_dts": torch.empty((P, 1), **fo),
             "dL_dscales": torch.empty((P, 3), **fo), "dL_dscales_t": torch.empty((P, 1), **fo),
             "dL_drotations": torch.empty((P, 4), **fo), "dL_drotations_r": torch.empty((P, 4), **fo),
-            "grad_accum": torch.empty((P, 16), **fo),  # packed blend-backward accumulators (scratch)
+            "grad_accum": None if grad_accum is not None else torch.empty((P, 16), **fo),  # packed blend-backward accumulators
         }
         if grad_out:
             for name, t in grad_out.items():
@@ -182,7 +184,12 @@ class _NativeRasterizer:
         ptrs = [_capi._ptr(g[k]) for k in (
             "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
             "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r")]
-        bout = _capi.FdgsBackwardOut(*ptrs, int(bool(accumulate)), _capi._ptr(g["grad_accum"]))
+        clean = 0
+        if grad_accum is not None:
+            if grad_accum.numel() != P * 16 or grad_accum.dtype != torch.float32 or not grad_accum.is_contiguous():
+                raise RuntimeError("fdgs: grad_accum must be a contiguous float32 tensor with %d elements" % (P * 16))
+            g["grad_accum"], clean = grad_accum, 1
+        bout = _capi.FdgsBackwardOut(*ptrs, int(bool(accumulate)), _capi._ptr(g["grad_accum"]), clean)
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
                                                    _capi.current_stream_handle(dev))

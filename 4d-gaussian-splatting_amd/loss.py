@@ -56,11 +56,12 @@ def fused_l1_ssim(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0
     return _FusedL1SSIM.apply(image, gt, lambda_dssim)
 
 
-def l1_ssim_value_and_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor):
-    """The same loss without autograd: returns ``(loss, d(upstream * loss)/d image)``.  ``upstream`` is a 1-element
-    float32 GPU tensor (e.g. 1 / batch_size).  Both kernels are enqueued on the current stream."""
+def l1_ssim_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor):
+    """Forward + backward kernels only: returns ``(d(upstream * loss)/d image, handle)``; ``l1_ssim_loss(handle)`` reduces
+    the per-tile partial sums to the loss value later (e.g. after the rasterizer backward has been enqueued, so that the
+    small reduction is off the critical path)."""
     if not image.is_cuda or not gt.is_cuda:
-        raise RuntimeError("fdgs: l1_ssim_value_and_grad needs GPU tensors; there is no CPU path")
+        raise RuntimeError("fdgs: l1_ssim_grad needs GPU tensors; there is no CPU path")
     img_c, gt_c = image.contiguous().float(), gt.contiguous().float()
     C, H, W = img_c.shape[-3], img_c.shape[-2], img_c.shape[-1]
     dev = img_c.device
@@ -75,8 +76,23 @@ def l1_ssim_value_and_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: 
         rc = _capi.lib.fdgs_l1_ssim_backward(img_c.data_ptr(), gt_c.data_ptr(), C, H, W, d1.data_ptr(), d2.data_ptr(),
                                              d3.data_ptr(), upstream.data_ptr(), float(lambda_dssim), g.data_ptr(), st)
         _capi._check(rc, "fdgs_l1_ssim_backward")
-        out = torch.empty(3, dtype=torch.float32, device=dev)
-        rc = _capi.lib.fdgs_l1_ssim_loss(parts[0].data_ptr(), parts[1].data_ptr(), nparts, C, H, W, float(lambda_dssim),
-                                         out.data_ptr(), st)
-        _capi._check(rc, "fdgs_l1_ssim_loss")
-    return out[0], g
+    return g, (parts, nparts, C, H, W, float(lambda_dssim))
+
+
+def l1_ssim_loss(handle) -> torch.Tensor:
+    """Loss value of a ``l1_ssim_grad`` call (deterministic reduction kernel, current stream)."""
+    parts, nparts, C, H, W, lam = handle
+    dev = parts.device
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _capi.lib.fdgs_l1_ssim_loss(parts[0].data_ptr(), parts[1].data_ptr(), nparts, C, H, W, lam, out.data_ptr(),
+                                         _capi.current_stream_handle(dev))
+    _capi._check(rc, "fdgs_l1_ssim_loss")
+    return out[0]
+
+
+def l1_ssim_value_and_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor):
+    """The same loss without autograd: returns ``(loss, d(upstream * loss)/d image)``.  ``upstream`` is a 1-element
+    float32 GPU tensor (e.g. 1 / batch_size).  All kernels are enqueued on the current stream."""
+    g, handle = l1_ssim_grad(image, gt, lambda_dssim, upstream)
+    return l1_ssim_loss(handle), g

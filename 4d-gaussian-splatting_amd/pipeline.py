@@ -18,7 +18,7 @@ from typing import List, Sequence
 import torch
 
 from .fused import raw_backward, raw_forward, raw_settings
-from .loss import l1_ssim_value_and_grad
+from .loss import l1_ssim_grad, l1_ssim_loss
 from .train_host import allreduce_and_step
 
 
@@ -34,6 +34,7 @@ class StepPipeline:
         self.sB = torch.cuda.Stream(dev) if overlap else self.sF
         self.sink = model.grad_sink()
         self._up = {}
+        self._gacc = None   # persistent, always-zero blend-backward accumulator (no memset per view)
 
     def _upstream(self, B):
         if B not in self._up:
@@ -51,6 +52,9 @@ class StepPipeline:
             self.sB.wait_stream(main)
         up = self._upstream(B)
         m = self.model
+        if self._gacc is None or self._gacc.shape[0] != m.P:
+            with torch.cuda.stream(self.sB):
+                self._gacc = torch.zeros((m.P, 16), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
         for b in range(B):
             with torch.cuda.stream(self.sF):
@@ -62,10 +66,11 @@ class StepPipeline:
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
                 self.sB.wait_event(ev)
-                loss, g_color = l1_ssim_value_and_grad(color, gts[b], self.lam, up)
+                g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
-                                     self.sink, b > 0)
+                                     self.sink, b > 0, grad_accum=self._gacc)
+                loss = l1_ssim_loss(loss_handle)   # the small reduction goes behind the backward, off the critical path
             # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
             keep.append((geom, binb, img, out_means3D, g_color, T))
             results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow,

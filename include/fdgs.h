@@ -155,7 +155,11 @@ typedef struct fdgs_backward_out
 	                           train.py:104-166).  The per-view outputs (dL_dmeans2D, dL_dcolors, dL_dflows,
 	                           dL_dcov3D) are always overwritten. */
 	float* grad_accum;      /* [P,16] scratch: packed per-Gaussian accumulators of the blend backward
-	                           (colour 3, flow 2, mean2D 3, conic xx/xy/yy 3 (Q12 convention), opacity 1, pad 4) */
+	                           (colour 3, depth 1, flow 2, mean2D 2, conic xx/yy/xy 3 (Q12 convention), opacity 1,
+	                           SH-backward mean / time 4) */
+	int32_t grad_accum_clean; /* 0: the call clears grad_accum itself (one memset per backward).
+	                             1: the caller guarantees it is all zero on entry (a persistent buffer, zeroed once) and
+	                                the call leaves it all zero on exit: the last kernel re-zeroes what it has read */
 } fdgs_backward_out;
 
 /* Forward pass: preprocess -> depth sort -> scan -> instance emission -> tile
