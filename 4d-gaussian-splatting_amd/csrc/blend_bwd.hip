@@ -179,11 +179,10 @@ namespace fdgs
 			if (AUX && dL_masks) dL_mask = dL_masks[pix_id];
 		}
 		const float nTf_bg = -T_final * (bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2);
-		const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H; // backward.cu:1010-1011
 
 		// After row_transpose_reduce12 lane L holds slot (L & 15) = word (L & 15) of the Gaussian's packed 64-byte
-		// accumulator record: colour r,g,b 0-2, depth 3, flow 4-5, mean2D x,y 6-7, conic xx,yy 8-9, conic xy 10,
-		// opacity 11.  One record = one 64-B segment, so the 12-lane atomic instruction is ONE memory-side
+		// accumulator record: colour r,g,b 0-2, depth 3, flow 4-5, then the moments of q = G dL/dalpha: q dx, q dy 6-7,
+		// q dx^2, q dy^2 8-9, q dx dy 10, q 11 (preprocess_bwd turns them into dL/dmean2D, dL/dconic, dL/dopacity).  One record = one 64-B segment, so the 12-lane atomic instruction is ONE memory-side
 		// request instead of five (the reference scatters into five arrays, backward.cu:1116-1133).
 		float* const slot_ptr = gacc + (lane & 15);
 		const bool slot_writer = lane < NG && (AUX || lane < 3 || lane > 5);
@@ -232,19 +231,19 @@ namespace fdgs
 				g[4] = dchannel_dcolor * dLf0;
 				g[5] = dchannel_dcolor * dLf1;
 			}
-			g[11] = G_e * dL_dalpha;
-			{
-				// dG/dd = -G Q d:  t = Q d
-				const float t1 = fmaf(ea.w, dy, ea.z * dx), t2 = fmaf(ea.w, dx, eb.x * dy);
-				const float k = eb.y * g[11];          // dL/dG * G
-				const float kh = -0.5f * k;
-				const float khx = kh * dx;
-				g[6] = (k * t1) * -ddelx_dx;
-				g[7] = (k * t2) * -ddely_dy;
-				g[8] = khx * dx;
-				g[9] = (kh * dy) * dy;
-				g[10] = khx * dy;
-			}
+			// Geometry slots: what has to be summed over the pixels are the MOMENTS of q = G dL/dalpha in the offset d from
+			// the Gaussian's centre -- q, q dx, q dy, q dx^2, q dy^2, q dx dy.  dL/dmean2D, dL/dconic and dL/dopacity are
+			// linear in them with per-Gaussian coefficients (conic, opacity, W/2, H/2: backward.cu:1107-1133), so that
+			// conversion runs once per Gaussian in preprocess_bwd instead of once per (pixel, Gaussian) here: 6 VALU
+			// instructions for these six slots instead of 16.
+			const float q = G_e * dL_dalpha;
+			const float qx = q * dx, qy = q * dy;
+			g[6] = qx;
+			g[7] = qy;
+			g[8] = qx * dx;
+			g[9] = qy * dy;
+			g[10] = qx * dy;
+			g[11] = q;
 			reduce_and_add<AUX>(g, slot_ptr, slot_writer, eid);
 		};
 

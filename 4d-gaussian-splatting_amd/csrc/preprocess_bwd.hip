@@ -36,6 +36,8 @@ namespace fdgs
 		const int32_t* radii; const float* means; /* out_means3D */
 		const float* cov3D; const uint8_t* clamped;
 		float* gacc; /* packed blend-backward accumulators [P,16], see blend_bwd.hip */
+		const float4* records; /* the forward's packed blend records (conic, effective opacity): geometry buffer */
+		float half_w, half_h;
 		int rezero; /* leave the record zero for the next backward (fdgs_backward_out.grad_accum_clean) */
 		float *dL_dmean2D, *dL_dcolor, *dL_dflows;
 		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
@@ -78,8 +80,19 @@ namespace fdgs
 		if (a.rezero) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z; }
 		const float3 g_color = make_float3(r0.x, r0.y, r0.z);
 		const float2 g_flow = make_float2(r1.x, r1.y);
-		const float3 g_mean2D = make_float3(r1.z, r1.w, r0.w);
-		const float3 g_conic = make_float3(r2.x, r2.z, r2.y);
+		// words 6-11 hold the pixel sums of q d^n (q = G dL/dalpha, d = mean2D - pixel); with the conic (A, B, C) and the
+		// effective opacity o of the forward's blend record (backward.cu:1107-1133):
+		//   dL/dmean2D = -o (W/2, H/2) * (A Mx + B My, B Mx + C My);  dL/dconic = -o/2 (Mxx, Mxy, Myy);  dL/do = M0
+		float3 g_mean2D = make_float3(0.f, 0.f, r0.w), g_conic = make_float3(0.f, 0.f, 0.f);
+		if (visible)   // culled Gaussians have no blend record (and all-zero moments)
+		{
+			const float4 ra = a.records[3 * (size_t)idx + 0], rb = a.records[3 * (size_t)idx + 1];
+			const float cA = ra.z, cB = ra.w, cC = rb.x, o_eff = rb.y;
+			const float Mx = r1.z, My = r1.w, Mxx = r2.x, Myy = r2.y, Mxy = r2.z;
+			g_mean2D.x = -o_eff * a.half_w * (cA * Mx + cB * My);
+			g_mean2D.y = -o_eff * a.half_h * (cB * Mx + cC * My);
+			g_conic = make_float3(-0.5f * o_eff * Mxx, -0.5f * o_eff * Mxy, -0.5f * o_eff * Myy);
+		}
 		float g_opacity = r2.w;
 
 		if (visible)
@@ -358,6 +371,8 @@ namespace fdgs
 		a.cov3D = reinterpret_cast<const float*>(geom + L.cov3D);
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.rezero = out.grad_accum_clean;
+		a.records = reinterpret_cast<const float4*>(geom + L.records);
+		a.half_w = 0.5f * s.W; a.half_h = 0.5f * s.H;   // ddelx_dx, ddely_dy (backward.cu:1010-1011)
 		a.dL_dmean2D = out.dL_dmeans2D; a.dL_dcolor = out.dL_dcolors; a.dL_dflows = out.dL_dflows;
 		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
 		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;
