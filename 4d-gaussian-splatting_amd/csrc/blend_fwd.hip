@@ -16,17 +16,21 @@
 
 namespace fdgs
 {
+	typedef float v2f __attribute__((ext_vector_type(2)));
+
 	__global__ void __launch_bounds__(WAVE) blend_fwd_kernel(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
 		int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
 		float* __restrict__ out_color, float* __restrict__ out_flow, float* __restrict__ out_depth, float* __restrict__ out_T,
 		float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 	{
-		// wave-private queue of the surviving entries of the current 64-entry chunk (+2: inert padding entry)
-		__shared__ float4 s_a[WAVE + 2];
-		__shared__ float4 s_b[WAVE + 2];
-		__shared__ float4 s_c[WAVE + 2];
-		__shared__ uint32_t s_pos[WAVE + 2];
+		// Wave-private queue of the surviving entries of the current 64-entry chunk, stored as PAIRS of entries with the
+		// two entries interleaved word by word: (x0,x1,y0,y1) (A0,A1,B0,B1) (C0,C1,o0,o1) (r0,r1,g0,g1) (b0,b1,d0,d1)
+		// (fx0,fx1,fy0,fy1).  One b128 read then delivers the same quantity of both entries in an aligned register
+		// pair, so the per-entry arithmetic up to alpha runs as packed fp32 (v_pk_*: two entries per instruction).
+		constexpr int QP = WAVE / 2 + 1;
+		__shared__ float4 s_q[6][QP];
+		__shared__ uint2 s_pp[QP];          // list position + 1 of the two entries (= n_contrib if it is the last contributor)
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -47,7 +51,7 @@ namespace fdgs
 		bool done = !inside;
 		float T = 1.0f;
 		uint32_t last_contributor = 0;
-		float C0 = 0.f, C1 = 0.f, C2 = 0.f, F0 = 0.f, F1 = 0.f, D = 0.f;
+		v2f acc_r = { 0.f, 0.f }, acc_g = acc_r, acc_b = acc_r, acc_d = acc_r, acc_fx = acc_r, acc_fy = acc_r;
 
 		for (int base = 0; base < n; base += WAVE)
 		{
@@ -68,49 +72,65 @@ namespace fdgs
 			if (keep)
 			{
 				const int slot = __popcll(mask & lt_mask);
-				s_a[slot] = a;
-				s_b[slot] = b;
-				s_c[slot] = records[3 * (size_t)id + 2];
-				s_pos[slot] = (uint32_t)pos;
+				const float4 c = records[3 * (size_t)id + 2];
+				const int pr = slot >> 1, h = slot & 1;
+				float* q0 = reinterpret_cast<float*>(&s_q[0][pr]) + h;
+				float* q1 = reinterpret_cast<float*>(&s_q[1][pr]) + h;
+				float* q2 = reinterpret_cast<float*>(&s_q[2][pr]) + h;
+				float* q3 = reinterpret_cast<float*>(&s_q[3][pr]) + h;
+				float* q4 = reinterpret_cast<float*>(&s_q[4][pr]) + h;
+				float* q5 = reinterpret_cast<float*>(&s_q[5][pr]) + h;
+				q0[0] = a.x; q0[2] = a.y; q1[0] = a.z; q1[2] = a.w; q2[0] = b.x; q2[2] = b.y;
+				q3[0] = b.z; q3[2] = b.w; q4[0] = c.x; q4[2] = c.y; q5[0] = c.z; q5[2] = c.w;
+				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[h] = (uint32_t)pos + 1u;
 			}
 			if (lane == 0 && (cnt & 1))
 			{
-				// inert padding so the 2x unrolled loop below needs no tail: opacity 0 -> alpha 0 -> rejected
-				s_a[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_b[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_c[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_pos[cnt] = 0u;
+				// inert second half of the last pair: opacity 0 -> alpha 0 -> rejected
+				const int pr = cnt >> 1;
+#pragma unroll
+				for (int k = 0; k < 6; k++) { float* q = reinterpret_cast<float*>(&s_q[k][pr]) + 1; q[0] = 0.f; q[2] = 0.f; }
+				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[1] = 0u;
 			}
 			__syncthreads(); // single-wave workgroup: orders the LDS writes before the cross-lane reads
 
-			// Branch-free inner loop, two entries per trip with all LDS reads issued up front: a wave's
-			// progress here is bound by its dependent-latency chain (LDS -> exp -> compares), not by issue
-			// rate, so the per-pixel tests of the reference (forward.cu:582-597) become predicates + selects.
-			for (int j = 0; j < cnt; j += 2)
+			// Branch-free inner loop, one PAIR of entries per trip.  Everything up to alpha is packed arithmetic on the two
+			// entries at once, with the reference's association per element (forward.cu:585-590); the transmittance
+			// logic (forward.cu:591-597) is sequential by nature and runs entry by entry on the halves; the six
+			// accumulators are kept as (even entries, odd entries) pairs and folded after the loop.
+			const int npairs = (cnt + 1) >> 1;
+			for (int i = 0; i < npairs; i++)
 			{
-				const float4 a0 = s_a[j], b0 = s_b[j], c0 = s_c[j];
-				const float4 a1 = s_a[j + 1], b1 = s_b[j + 1], c1 = s_c[j + 1];
-				const uint32_t p0 = s_pos[j], p1 = s_pos[j + 1];
-#define FDGS_BLEND_ONE(ea, eb, ec, epos)                                                                  \
+				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i], Q5 = s_q[5][i];
+				const uint2 pp = s_pp[i];
+				const v2f dx = v2f{ Q0.x, Q0.y } - pixfx, dy = v2f{ Q0.z, Q0.w } - pixfy;
+				const v2f cA = { Q1.x, Q1.y }, cB = { Q1.z, Q1.w }, cC = { Q2.x, Q2.y }, op = { Q2.z, Q2.w };
+				const v2f s2 = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
+				const v2f power = __builtin_elementwise_fma(v2f{ -0.5f, -0.5f }, s2, -((cB * dx) * dy));
+				const v2f e2 = power * 1.4426950408889634f;
+				const v2f al = op * v2f{ __builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y) };
+				const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+				v2f w;
+#define FDGS_BLEND_STEP(alpha, pw, pos1, wout)                                                            \
 				{                                                                                         \
-					const float dx = ea.x - pixfx, dy = ea.y - pixfy;                                     \
-					const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;      \
-					const float alpha = fminf(0.99f, eb.y * fast_exp(power));                             \
 					const float test_T = T * (1.0f - alpha);                                              \
-					const bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);             \
+					const bool valid = !done && !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);                \
 					const bool stop = valid && (test_T < 0.0001f);                                        \
 					const bool contrib = valid && !stop;                                                  \
-					const float w = contrib ? alpha * T : 0.0f;                                           \
-					C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;                                       \
-					D += ec.y * w;                                                                        \
-					F0 += ec.z * w; F1 += ec.w * w;                                                       \
+					wout = contrib ? alpha * T : 0.0f;                                                    \
 					T = contrib ? test_T : T;                                                             \
-					last_contributor = contrib ? epos + 1u : last_contributor;                            \
+					last_contributor = contrib ? pos1 : last_contributor;                                 \
 					done = done || stop;                                                                  \
 				}
-				FDGS_BLEND_ONE(a0, b0, c0, p0)
-				FDGS_BLEND_ONE(a1, b1, c1, p1)
-#undef FDGS_BLEND_ONE
+				FDGS_BLEND_STEP(alpha0, power.x, pp.x, w.x)
+				FDGS_BLEND_STEP(alpha1, power.y, pp.y, w.y)
+#undef FDGS_BLEND_STEP
+				acc_r = __builtin_elementwise_fma(v2f{ Q3.x, Q3.y }, w, acc_r);
+				acc_g = __builtin_elementwise_fma(v2f{ Q3.z, Q3.w }, w, acc_g);
+				acc_b = __builtin_elementwise_fma(v2f{ Q4.x, Q4.y }, w, acc_b);
+				acc_d = __builtin_elementwise_fma(v2f{ Q4.z, Q4.w }, w, acc_d);
+				acc_fx = __builtin_elementwise_fma(v2f{ Q5.x, Q5.y }, w, acc_fx);
+				acc_fy = __builtin_elementwise_fma(v2f{ Q5.z, Q5.w }, w, acc_fy);
 				if (__ballot(!done) == 0ull) break;
 			}
 			__syncthreads(); // the queue is rewritten by the next chunk
@@ -122,12 +142,12 @@ namespace fdgs
 			final_T[pix_id] = T;
 			out_T[pix_id] = T;
 			n_contrib[pix_id] = last_contributor;
-			out_color[0 * HW + pix_id] = C0 + T * bg[0];
-			out_color[1 * HW + pix_id] = C1 + T * bg[1];
-			out_color[2 * HW + pix_id] = C2 + T * bg[2];
-			out_flow[0 * HW + pix_id] = F0;
-			out_flow[1 * HW + pix_id] = F1;
-			out_depth[pix_id] = D;
+			out_color[0 * HW + pix_id] = (acc_r.x + acc_r.y) + T * bg[0];
+			out_color[1 * HW + pix_id] = (acc_g.x + acc_g.y) + T * bg[1];
+			out_color[2 * HW + pix_id] = (acc_b.x + acc_b.y) + T * bg[2];
+			out_flow[0 * HW + pix_id] = acc_fx.x + acc_fx.y;
+			out_flow[1 * HW + pix_id] = acc_fy.x + acc_fy.y;
+			out_depth[pix_id] = acc_d.x + acc_d.y;
 		}
 	}
 
