@@ -131,6 +131,8 @@ namespace fdgs
 
 	// AUX = false: only the colour image carries an upstream gradient (dL_dout_depth / _alpha / _flow are NULL = zero),
 	// the usual case in training (photometric loss on the render only): the depth / flow / mask terms drop out.
+	typedef float v2f __attribute__((ext_vector_type(2)));
+
 	template <bool AUX>
 	__global__ void __launch_bounds__(WAVE) blend_bwd_kernel(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
@@ -140,12 +142,13 @@ namespace fdgs
 		const float* __restrict__ dL_dpix_flow,
 		float* __restrict__ gacc)
 	{
-		// wave-private queue of the surviving entries of the current chunk (+2: inert padding entries for the prefetch)
-		__shared__ float4 s_a[WAVE + 2];
-		__shared__ float4 s_b[WAVE + 2];
-		__shared__ float4 s_c[WAVE + 2];
-		__shared__ uint32_t s_pos[WAVE + 2];
-		__shared__ uint32_t s_id[WAVE + 2];
+		// Wave-private queue of the surviving entries of the current chunk, stored as PAIRS of entries interleaved word by
+		// word, as in blend_fwd.hip: (x0,x1,y0,y1) (A0,A1,B0,B1) (C0,C1,o0,o1) (r0,r1,g0,g1) (b0,b1,d0,d1) (fx0,fx1,fy0,fy1):
+		// the arithmetic up to alpha runs as packed fp32 on two entries per instruction.
+		constexpr int QP = WAVE / 2 + 1;
+		__shared__ float4 s_q[6][QP];
+		__shared__ uint2 s_pp[QP];   // list positions of the two entries
+		__shared__ uint2 s_ii[QP];   // their Gaussian ids
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -189,16 +192,11 @@ namespace fdgs
 
 		float S = 0.f, Lc = 0.f, last_alpha = 0.f;
 
-		// One queue entry against this lane's pixel.  (ea, eb, ec) = the packed record, epos = list position.
-		auto entry = [&](const float4 ea, const float4 eb, const float4 ec, const uint32_t epos, const uint32_t eid) __attribute__((always_inline))
+		// One queue entry against this lane's pixel, after the packed head: d = mean2D - pixel, power, G = exp(power), alpha;
+		// colour (cr, cg, cb), depth, flow of the entry; epos = list position, eid = Gaussian id.
+		auto entry = [&](const float dx, const float dy, const float power, const float G, const float alpha, const float cr, const float cg,
+		                 const float cb, const float cdepth, const float cfx, const float cfy, const uint32_t epos, const uint32_t eid) __attribute__((always_inline))
 		{
-			const float dx = ea.x - pixfx, dy = ea.y - pixfy;
-			// the reference's own association (forward.cu:585, backward.cu:1036): keeps alpha -- and with it the
-			// alpha >= 1/255 decision -- within an ulp of the oracle's; a cheaper factored form was measured to flip
-			// cliff pairs (2 Gaussians in 30000 off by 1e-3 of the gradient scale) and was dropped
-			const float power = -0.5f * (ea.z * dx * dx + eb.x * dy * dy) - ea.w * dx * dy;
-			const float G = fast_exp(power);
-			const float alpha = fminf(0.99f, eb.y * G);
 			// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
 			const bool active = ((int)epos < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 			if (__ballot(active) == 0ull) return;
@@ -214,8 +212,8 @@ namespace fdgs
 			// the coefficients and dL_k is a per-pixel constant, so they collapse into ONE scalar recurrence on
 			// S = sum_k acc_k dL_k with  last = sum_k c_k dL_k  (c_mask = 1):  same value up to fp32 rounding.
 			float Cd;
-			if constexpr (AUX) Cd = fmaf(eb.z, dLp0, fmaf(eb.w, dLp1, fmaf(ec.x, dLp2, fmaf(ec.z, dLf0, fmaf(ec.w, dLf1, fmaf(ec.y, dL_depth, dL_mask))))));
-			else Cd = fmaf(eb.z, dLp0, fmaf(eb.w, dLp1, ec.x * dLp2));
+			if constexpr (AUX) Cd = fmaf(cr, dLp0, fmaf(cg, dLp1, fmaf(cb, dLp2, fmaf(cfx, dLf0, fmaf(cfy, dLf1, fmaf(cdepth, dL_depth, dL_mask))))));
+			else Cd = fmaf(cr, dLp0, fmaf(cg, dLp1, cb * dLp2));
 			S = fmaf(last_alpha, Lc - S, S);
 			Lc = Cd;
 			last_alpha = alpha_e;
@@ -265,35 +263,48 @@ namespace fdgs
 			const int cnt = __popcll(mask);
 			if (keep)
 			{
-				const int q = __popcll(mask & lt_mask); // back-to-front order is preserved
-				s_a[q] = a;
-				s_b[q] = b;
-				s_c[q] = records[3 * (size_t)id + 2];
-				s_pos[q] = (uint32_t)pos;
-				s_id[q] = id;
+				const int slot = __popcll(mask & lt_mask); // back-to-front order is preserved
+				const float4 c = records[3 * (size_t)id + 2];
+				const int pr = slot >> 1, h = slot & 1;
+				float* q0 = reinterpret_cast<float*>(&s_q[0][pr]) + h;
+				float* q1 = reinterpret_cast<float*>(&s_q[1][pr]) + h;
+				float* q2 = reinterpret_cast<float*>(&s_q[2][pr]) + h;
+				float* q3 = reinterpret_cast<float*>(&s_q[3][pr]) + h;
+				float* q4 = reinterpret_cast<float*>(&s_q[4][pr]) + h;
+				float* q5 = reinterpret_cast<float*>(&s_q[5][pr]) + h;
+				q0[0] = a.x; q0[2] = a.y; q1[0] = a.z; q1[2] = a.w; q2[0] = b.x; q2[2] = b.y;
+				q3[0] = b.z; q3[2] = b.w; q4[0] = c.x; q4[2] = c.y; q5[0] = c.z; q5[2] = c.w;
+				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[h] = (uint32_t)pos;
+				(reinterpret_cast<uint32_t*>(&s_ii[pr]))[h] = id;
 			}
-			if (lane < 2)
+			if (lane == 0 && (cnt & 1))
 			{
-				// inert entries behind the queue so the prefetch never reads stale data
-				s_a[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_b[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_c[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-				s_pos[cnt + lane] = 0x7fffffffu;
-				s_id[cnt + lane] = 0u;
+				// inert second half of the last pair: list position beyond every last contributor -> never active
+				const int pr = cnt >> 1;
+#pragma unroll
+				for (int k = 0; k < 6; k++) { float* q = reinterpret_cast<float*>(&s_q[k][pr]) + 1; q[0] = 0.f; q[2] = 0.f; }
+				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[1] = 0x7fffffffu;
+				(reinterpret_cast<uint32_t*>(&s_ii[pr]))[1] = 0u;
 			}
 			__syncthreads();
 
-			// software pipeline: entry j is in registers, entry j+1 is fetched now and lands while j is processed
-			float4 a0 = s_a[0], b0 = s_b[0], c0 = s_c[0];
-			uint32_t p0 = s_pos[0], i0 = s_id[0];
-			for (int j = 0; j < cnt; j += 2)
+			const int npairs = (cnt + 1) >> 1;
+			for (int i = 0; i < npairs; i++)
 			{
-				// unrolled by two with ping-pong register sets: no register rotation between iterations
-				const float4 a1 = s_a[j + 1], b1 = s_b[j + 1], c1 = s_c[j + 1];
-				const uint32_t p1 = s_pos[j + 1], i1 = s_id[j + 1];
-				entry(a0, b0, c0, p0, i0);
-				a0 = s_a[j + 2]; b0 = s_b[j + 2]; c0 = s_c[j + 2]; p0 = s_pos[j + 2]; i0 = s_id[j + 2];
-				entry(a1, b1, c1, p1, i1); // the inert padding entry when j + 1 == cnt: skipped by its own test
+				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i], Q5 = s_q[5][i];
+				const uint2 pp = s_pp[i], ii = s_ii[i];
+				// packed head for both entries, with the reference's association per element (forward.cu:585,
+				// backward.cu:1036): keeps alpha -- and with it the alpha >= 1/255 decision -- within an ulp of the oracle's
+				// (a cheaper factored form flipped cliff pairs and was dropped)
+				const v2f dx = v2f{ Q0.x, Q0.y } - pixfx, dy = v2f{ Q0.z, Q0.w } - pixfy;
+				const v2f cA = { Q1.x, Q1.y }, cB = { Q1.z, Q1.w }, cC = { Q2.x, Q2.y }, op = { Q2.z, Q2.w };
+				const v2f s2 = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
+				const v2f power = __builtin_elementwise_fma(v2f{ -0.5f, -0.5f }, s2, -((cB * dx) * dy));
+				const v2f e2 = power * 1.4426950408889634f;
+				const v2f G = { __builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y) };
+				const v2f al = op * G;
+				entry(dx.x, dy.x, power.x, G.x, fminf(0.99f, al.x), Q3.x, Q3.z, Q4.x, Q4.z, Q5.x, Q5.z, pp.x, ii.x);
+				entry(dx.y, dy.y, power.y, G.y, fminf(0.99f, al.y), Q3.y, Q3.w, Q4.y, Q4.w, Q5.y, Q5.w, pp.y, ii.y);
 			}
 			__syncthreads();
 		}
