@@ -193,14 +193,11 @@ namespace fdgs
 		float S = 0.f, Lc = 0.f, last_alpha = 0.f;
 
 		// One queue entry against this lane's pixel, after the packed head: d = mean2D - pixel, power, G = exp(power), alpha;
-		// colour (cr, cg, cb), depth, flow of the entry; epos = list position, eid = Gaussian id.
+		// colour (cr, cg, cb), depth, flow of the entry; active = this pixel takes part; eid = Gaussian id.
 		auto entry = [&](const float dx, const float dy, const float power, const float G, const float alpha, const float cr, const float cg,
-		                 const float cb, const float cdepth, const float cfx, const float cfy, const uint32_t epos, const uint32_t eid) __attribute__((always_inline))
+		                 const float cb, const float cdepth, const float cfx, const float cfy, const bool active, const uint32_t eid) __attribute__((always_inline))
 		{
-			// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
-			const bool active = ((int)epos < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-			if (__ballot(active) == 0ull) return;
-			// Branch-free from here: a lane that skips this entry runs the same instructions with
+			// Branch-free: a lane that skips this entry runs the same instructions with
 			// alpha = G = 0, which leaves T and the recurrence unchanged and makes all 12 products zero.
 			const float alpha_e = active ? alpha : 0.0f;
 			const float G_e = active ? G : 0.0f;
@@ -243,6 +240,45 @@ namespace fdgs
 			g[10] = qx * dy;
 			g[11] = q;
 			reduce_and_add<AUX>(g, slot_ptr, slot_writer, eid);
+		};
+
+		// Both entries of a pair have contributing pixels (the common case): the same arithmetic as `entry` twice, but
+		// everything that is not part of the sequential T / S recurrences runs packed on the two entries.
+		auto entry_pair = [&](const v2f dx, const v2f dy, const v2f G, const float alpha0, const float alpha1, const v2f cr, const v2f cg,
+		                      const v2f cb, const v2f cdepth, const v2f cfx, const v2f cfy, const bool act0, const bool act1,
+		                      const uint32_t eid0, const uint32_t eid1) __attribute__((always_inline))
+		{
+			const v2f alpha_e = { act0 ? alpha0 : 0.0f, act1 ? alpha1 : 0.0f };
+			const v2f G_e = { act0 ? G.x : 0.0f, act1 ? G.y : 0.0f };
+			const v2f om = 1.0f - alpha_e;
+			const v2f inv = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
+			const float T0 = T * inv.x, T1 = T0 * inv.y;
+			T = T1;
+			const v2f Tp = { T0, T1 };
+			const v2f dcd = alpha_e * Tp;
+			v2f Cd;
+			if constexpr (AUX) Cd = cr * dLp0 + (cg * dLp1 + (cb * dLp2 + (cfx * dLf0 + (cfy * dLf1 + (cdepth * dL_depth + dL_mask)))));
+			else Cd = __builtin_elementwise_fma(cr, v2f{ dLp0, dLp0 }, __builtin_elementwise_fma(cg, v2f{ dLp1, dLp1 }, cb * dLp2));
+			const float S0 = fmaf(last_alpha, Lc - S, S);
+			const float S1 = fmaf(alpha_e.x, Cd.x - S0, S0);
+			S = S1; Lc = Cd.y; last_alpha = alpha_e.y;
+			const v2f Sp = { S0, S1 };
+			const v2f dL_dalpha = __builtin_elementwise_fma(Cd - Sp, Tp, inv * nTf_bg);
+			const v2f g0 = dcd * dLp0, g1 = dcd * dLp1, g2 = dcd * dLp2;
+			const v2f q = G_e * dL_dalpha;
+			const v2f qx = q * dx, qy = q * dy;
+			const v2f qxx = qx * dx, qyy = qy * dy, qxy = qx * dy;
+			float ga[12], gb[12];
+			ga[0] = g0.x; ga[1] = g1.x; ga[2] = g2.x; gb[0] = g0.y; gb[1] = g1.y; gb[2] = g2.y;
+			if constexpr (AUX)
+			{
+				const v2f g3 = dcd * dL_depth, g4 = dcd * dLf0, g5 = dcd * dLf1;
+				ga[3] = g3.x; ga[4] = g4.x; ga[5] = g5.x; gb[3] = g3.y; gb[4] = g4.y; gb[5] = g5.y;
+			}
+			ga[6] = qx.x; ga[7] = qy.x; ga[8] = qxx.x; ga[9] = qyy.x; ga[10] = qxy.x; ga[11] = q.x;
+			gb[6] = qx.y; gb[7] = qy.y; gb[8] = qxx.y; gb[9] = qyy.y; gb[10] = qxy.y; gb[11] = q.y;
+			reduce_and_add<AUX>(ga, slot_ptr, slot_writer, eid0);
+			reduce_and_add<AUX>(gb, slot_ptr, slot_writer, eid1);
 		};
 
 		for (int top = wave_last; top > 0; top -= WAVE)
@@ -303,8 +339,16 @@ namespace fdgs
 				const v2f e2 = power * 1.4426950408889634f;
 				const v2f G = { __builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y) };
 				const v2f al = op * G;
-				entry(dx.x, dy.x, power.x, G.x, fminf(0.99f, al.x), Q3.x, Q3.z, Q4.x, Q4.z, Q5.x, Q5.z, pp.x, ii.x);
-				entry(dx.y, dy.y, power.y, G.y, fminf(0.99f, al.y), Q3.y, Q3.w, Q4.y, Q4.w, Q5.y, Q5.w, pp.y, ii.y);
+				const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+				// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
+				const bool act0 = ((int)pp.x < last_contributor) && !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
+				const bool act1 = ((int)pp.y < last_contributor) && !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
+				const bool any0 = __ballot(act0) != 0ull, any1 = __ballot(act1) != 0ull;
+				if (any0 && any1)
+					entry_pair(dx, dy, G, alpha0, alpha1, v2f{ Q3.x, Q3.y }, v2f{ Q3.z, Q3.w }, v2f{ Q4.x, Q4.y }, v2f{ Q4.z, Q4.w },
+					           v2f{ Q5.x, Q5.y }, v2f{ Q5.z, Q5.w }, act0, act1, ii.x, ii.y);
+				else if (any0) entry(dx.x, dy.x, power.x, G.x, alpha0, Q3.x, Q3.z, Q4.x, Q4.z, Q5.x, Q5.z, act0, ii.x);
+				else if (any1) entry(dx.y, dy.y, power.y, G.y, alpha1, Q3.y, Q3.w, Q4.y, Q4.w, Q5.y, Q5.w, act1, ii.y);
 			}
 			__syncthreads();
 		}
