@@ -72,7 +72,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
-            "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
+            "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
 
 
@@ -126,6 +126,11 @@ def _load():
     lib.fdgs_densify_gather.restype = C.c_int
     lib.fdgs_densify_split.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 14
     lib.fdgs_densify_split.restype = C.c_int
+    lib.fdgs_densify_stats_local.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+    lib.fdgs_densify_stats_local.restype = C.c_int
+    lib.fdgs_densify_stats_apply.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 5
+    lib.fdgs_densify_stats_apply.restype = C.c_int
     lib.fdgs_knn_scratch_bytes.argtypes = [C.c_int32]
     lib.fdgs_knn_scratch_bytes.restype = C.c_size_t
     lib.fdgs_dist2_knn3.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

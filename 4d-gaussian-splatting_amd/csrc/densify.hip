@@ -152,6 +152,78 @@ namespace fdgs
 	}
 }
 
+namespace fdgs
+{
+	constexpr int STATS_MAX_VIEWS = 16;
+	struct StatsViews { const int32_t* radii[STATS_MAX_VIEWS]; const float* grad[STATS_MAX_VIEWS]; int n; };
+
+	// train.py:164-172 for this rank's views: visibility count, max radius, sum of ||dL/dmean2D.xy||
+	__global__ void __launch_bounds__(256) densify_stats_local_kernel(int P, const StatsViews v, float* __restrict__ count,
+	                                                                  float* __restrict__ pgrad, float* __restrict__ radii_max)
+	{
+		const int i = blockIdx.x * blockDim.x + threadIdx.x;
+		if (i >= P) return;
+		float c = 0.f, g = 0.f;
+		int r = 0;
+		for (int k = 0; k < v.n; k++)
+		{
+			const int rk = v.radii[k][i];
+			c += rk > 0 ? 1.f : 0.f;
+			r = max(r, rk);
+			const float gx = v.grad[k][3 * (size_t)i], gy = v.grad[k][3 * (size_t)i + 1];
+			g += sqrtf(gx * gx + gy * gy);
+		}
+		count[i] = c; pgrad[i] = g; radii_max[i] = (float)r;
+	}
+
+	// train.py:173-184, 229-236 + gaussian_model.py:637-642 on the (all-reduced) per-Gaussian sums
+	__global__ void __launch_bounds__(256) densify_stats_apply_kernel(int P, const float* __restrict__ count, const float* __restrict__ pgrad,
+	                                                                  const float* __restrict__ radii_max, const float* __restrict__ t_grad,
+	                                                                  float global_batch, float* __restrict__ xyz_acc, float* __restrict__ t_acc,
+	                                                                  float* __restrict__ denom, float* __restrict__ max_radii2D)
+	{
+		const int i = blockIdx.x * blockDim.x + threadIdx.x;
+		if (i >= P) return;
+		const float c = count[i];
+		if (!(c > 0.f)) return;
+		max_radii2D[i] = fmaxf(max_radii2D[i], radii_max[i]);
+		xyz_acc[i] += pgrad[i] * global_batch / c;
+		denom[i] += 1.0f;
+		if (t_grad) t_acc[i] += t_grad[i] * global_batch / c;
+	}
+}
+
+extern "C" int fdgs_densify_stats_local(int32_t P, int32_t num_views, const int32_t* const* radii, const float* const* viewspace_grad,
+                                        float* count, float* pgrad, float* radii_max, void* stream)
+{
+	using namespace fdgs;
+	if (P < 0 || num_views < 1 || num_views > STATS_MAX_VIEWS || !radii || !viewspace_grad) return FDGS_ERR_INVALID_ARG;
+	if (P == 0) return FDGS_OK;
+	if (!count || !pgrad || !radii_max) return FDGS_ERR_INVALID_ARG;
+	StatsViews v;
+	v.n = num_views;
+	for (int k = 0; k < num_views; k++)
+	{
+		if (!radii[k] || !viewspace_grad[k]) return FDGS_ERR_INVALID_ARG;
+		v.radii[k] = radii[k]; v.grad[k] = viewspace_grad[k];
+	}
+	hipLaunchKernelGGL(densify_stats_local_kernel, dim3(div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, P, v, count, pgrad, radii_max);
+	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
+}
+
+extern "C" int fdgs_densify_stats_apply(int32_t P, const float* count, const float* pgrad, const float* radii_max, const float* t_grad,
+                                        float global_batch, float* xyz_gradient_accum, float* t_gradient_accum, float* denom,
+                                        float* max_radii2D, void* stream)
+{
+	using namespace fdgs;
+	if (P < 0) return FDGS_ERR_INVALID_ARG;
+	if (P == 0) return FDGS_OK;
+	if (!count || !pgrad || !radii_max || !xyz_gradient_accum || !denom || !max_radii2D || (t_grad && !t_gradient_accum)) return FDGS_ERR_INVALID_ARG;
+	hipLaunchKernelGGL(densify_stats_apply_kernel, dim3(div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, P, count, pgrad, radii_max, t_grad,
+	                   global_batch, xyz_gradient_accum, t_gradient_accum, denom, max_radii2D);
+	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
+}
+
 extern "C" int fdgs_densify_classify(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,
                                      const float* opacity_raw, const float* max_radii2D, float max_grad, float min_opacity,
                                      float extent, float max_screen_size, float percent_dense, int32_t N, int32_t prune_only,

@@ -81,6 +81,9 @@ class DensificationStats:
         """``results``: this rank's per-view outputs of StepPipeline.step (radii, viewspace_grad = dL/dmeans2D with the
         loss scaled by 1/global_batch, as train.py:162); ``t_grad``: the accumulated, all-reduced dL/dt [P,1].
         train.py:164-184 with batch_size = global_batch."""
+        if self.xyz_gradient_accum.is_cuda:
+            self._update_gpu(results, t_grad, global_batch)
+            return
         vis = torch.stack([r["radii"] > 0 for r in results], 1)
         count = vis.sum(1).to(torch.float32)
         radii = torch.stack([r["radii"] for r in results], 1).max(1)[0].to(torch.float32)
@@ -100,6 +103,34 @@ class DensificationStats:
         if t_grad is not None:
             tg = torch.where(seen, t_grad[:, 0] * float(global_batch) / cnt, t_grad[:, 0]).unsqueeze(1)
             self.t_gradient_accum[seen] += tg[seen]                                    # train.py:178-181, gaussian_model.py:641
+
+
+    def _update_gpu(self, results, t_grad, global_batch):
+        """The same update in two small kernels (csrc/densify.hip) instead of ~25 PyTorch ops over [P] tensors (1.4 ms per
+        step at 300 k Gaussians -- a quarter of the step -- against 20 us)."""
+        import ctypes as C
+        from . import _capi
+        dev = self.xyz_gradient_accum.device
+        P, n = self.xyz_gradient_accum.shape[0], len(results)
+        radii = [r["radii"].contiguous() for r in results]
+        grads = [r["viewspace_grad"].contiguous() for r in results]
+        rp = (C.c_void_p * n)(*[t.data_ptr() for t in radii])
+        gp = (C.c_void_p * n)(*[t.data_ptr() for t in grads])
+        tmp = torch.empty((3, P), dtype=torch.float32, device=dev)   # count, pgrad | radii_max
+        st = _capi.current_stream_handle(dev)
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_densify_stats_local(P, n, rp, gp, tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), st)
+            _capi._check(rc, "fdgs_densify_stats_local")
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(tmp[:2], op=dist.ReduceOp.SUM)
+                dist.all_reduce(tmp[2], op=dist.ReduceOp.MAX)
+            tg = None if t_grad is None else t_grad.contiguous()
+            rc = _capi.lib.fdgs_densify_stats_apply(P, tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(),
+                                                    None if tg is None else tg.data_ptr(), float(global_batch),
+                                                    self.xyz_gradient_accum.data_ptr(), self.t_gradient_accum.data_ptr(),
+                                                    self.denom.data_ptr(), self.max_radii2D.data_ptr(), st)
+            _capi._check(rc, "fdgs_densify_stats_apply")
 
 
 def psnr(img: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:

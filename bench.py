@@ -57,8 +57,9 @@ ALGO_BYTES = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps before anything is measured (the shader clock takes ~100 ms of load to settle)")
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--views-per-step", type=int, default=4,
                     help="views rendered per rank and optimizer step (the reference's DyNeRF configs: batch_size 4, "

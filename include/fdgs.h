@@ -265,6 +265,17 @@ int fdgs_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 #define FDGS_DENSIFY_SPLIT 2        /* replace it by N samples (:487-543)                                       */
 #define FDGS_DENSIFY_PRUNE 4        /* the Gaussian (and its clone) fails the final prune test (:598-603)       */
 #define FDGS_DENSIFY_PRUNE_CHILD 8  /* its split children (scaling / (0.8 N)) fail the final prune test         */
+/* Densification statistics of one optimizer step (train.py:164-184, 229-236; gaussian_model.py:637-642), two phases so
+ * that the per-Gaussian sums can be all-reduced in between (count, pgrad: SUM; radii_max: MAX):
+ *   local: this rank's views -> count = #views with radius > 0, pgrad = sum of ||dL/dmean2D.xy||, radii_max (all [P] float);
+ *   apply: for Gaussians seen at least once, max_radii2D = max(., radii_max), xyz_gradient_accum += pgrad * batch / count,
+ *          denom += 1, t_gradient_accum += t_grad * batch / count (t_grad NULL: skipped).
+ * radii / viewspace_grad: HOST arrays of num_views (<= 16) device pointers ([P] int32, [P,3] float). */
+int fdgs_densify_stats_local(int32_t P, int32_t num_views, const int32_t* const* radii, const float* const* viewspace_grad,
+                             float* count, float* pgrad, float* radii_max, void* stream);
+int fdgs_densify_stats_apply(int32_t P, const float* count, const float* pgrad, const float* radii_max, const float* t_grad,
+                             float global_batch, float* xyz_gradient_accum, float* t_gradient_accum, float* denom,
+                             float* max_radii2D, void* stream);
 /* Per-Gaussian decision flags from the densification statistics.  max_screen_size <= 0: no size test
  * (`if max_screen_size:`); percent_dense, extent: as training_setup / cameras_extent; prune_only as in :584. */
 int fdgs_densify_classify(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling_raw,

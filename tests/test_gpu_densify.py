@@ -116,3 +116,20 @@ def test_densify_larger_scene_vs_oracle_and_training_continues(gpu_device):
         results, losses = sp.step(cams, gts, pipe, bg)
     torch.cuda.synchronize()
     assert results[0]["radii"].shape[0] == model.P and torch.isfinite(model.flat).all() and not torch.equal(before, model.flat)
+
+
+def test_stats_update_gpu_matches_host_statement(gpu_device):
+    """DensificationStats.update on the GPU (two kernels) equals the PyTorch statement of train.py:164-184 run on the CPU."""
+    from fdgs import harness
+    P, B = 5000, 4
+    g = torch.Generator().manual_seed(21)
+    gpu = harness.DensificationStats(P, gpu_device, 1)
+    cpu = harness.DensificationStats(P, "cpu", 1)
+    for _ in range(3):
+        radii = [torch.randint(-3, 12, (P,), generator=g).clamp(min=0).to(torch.int32) for _ in range(B)]
+        grads = [torch.randn(P, 3, generator=g) for _ in range(B)]
+        t_grad = torch.randn(P, 1, generator=g)
+        cpu.update([{"radii": r, "viewspace_grad": x} for r, x in zip(radii, grads)], t_grad, B)
+        gpu.update([{"radii": r.to(gpu_device), "viewspace_grad": x.to(gpu_device)} for r, x in zip(radii, grads)], t_grad.to(gpu_device), B)
+    for name in ("xyz_gradient_accum", "t_gradient_accum", "denom", "max_radii2D"):
+        np.testing.assert_allclose(getattr(gpu, name).cpu().numpy(), getattr(cpu, name).numpy(), rtol=2e-6, atol=1e-7, err_msg=name)
