@@ -269,6 +269,76 @@ namespace fdgs
 		return wbase + incl - v;
 	}
 
+	// Single pass with decoupled look-back: every workgroup scans its 1024-element chunk, publishes its total as an
+	// AGGREGATE, looks back over its predecessors' published words (a whole wave at a time: 64 predecessors per load)
+	// until it meets one that already carries an inclusive PREFIX, publishes its own prefix and writes its offsets.
+	// One launch instead of three (reduce / scan of the chunk sums / final).  A word = flag << 62 | value, written and
+	// read whole, so no fences are needed; the words must be zero on entry (the forward's first kernel clears them).
+	// Safe only while all workgroups are resident at once (they spin on lower-numbered workgroups), hence the
+	// three-launch fallback for very large P.
+	constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_FLAGS = 3ull << 62;
+
+	__global__ void __launch_bounds__(256) offsets_lookback_kernel(const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ order,
+	                                                              int P, unsigned long long* __restrict__ state, uint32_t* __restrict__ total_out,
+	                                                              uint32_t* __restrict__ offsets)
+	{
+		constexpr int IT = SCAN_CHUNK / 256;   // consecutive elements per thread
+		__shared__ uint32_t smem[16];
+		__shared__ uint32_t total_s, excl_s;
+		const int b = blockIdx.x, nblocks = gridDim.x;
+		const int first_j = b * SCAN_CHUNK + threadIdx.x * IT;
+		// serial scan of the thread's IT elements, one workgroup scan of the thread totals
+		uint32_t ex[IT], run = 0;
+#pragma unroll
+		for (int i = 0; i < IT; i++)
+		{
+			const int j = first_j + i;
+			const uint32_t v = (j < P) ? tiles[order[j]] : 0u;
+			ex[i] = run;
+			run += v;
+		}
+		const uint32_t tbase = block_excl_scan_256(run, &total_s, smem);
+		__syncthreads();
+		const uint32_t chunk_total = total_s;
+		if (threadIdx.x < WAVE)
+		{
+			const int lane = threadIdx.x;
+			if (lane == 0)
+				__hip_atomic_store(&state[b], (b == 0 ? LB_PREFIX : LB_AGG) | chunk_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			uint32_t excl = 0;
+			for (int j = b - 1; j >= 0; j -= WAVE)
+			{
+				const int idx = j - lane;   // lane 0 looks at the nearest predecessor
+				unsigned long long st = LB_PREFIX; // virtual predecessor of workgroup 0: prefix 0
+				if (idx >= 0)
+				{
+					do { st = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((st & LB_FLAGS) == 0ull);
+				}
+				const unsigned long long pmask = __ballot((st & LB_FLAGS) == LB_PREFIX);
+				const int first = pmask ? __ffsll((long long)pmask) - 1 : WAVE;   // nearest predecessor that already has a prefix
+				uint32_t v = (lane <= first) ? (uint32_t)(st & 0xFFFFFFFFull) : 0u;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+				excl += v;
+				if (pmask) break;
+			}
+			if (lane == 0)
+			{
+				if (b > 0) __hip_atomic_store(&state[b], LB_PREFIX | (unsigned long long)(excl + chunk_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				excl_s = excl;
+				if (b == nblocks - 1) *total_out = excl + chunk_total;
+			}
+		}
+		__syncthreads();
+		const uint32_t base = excl_s + tbase;
+#pragma unroll
+		for (int i = 0; i < IT; i++)
+		{
+			const int j = first_j + i;
+			if (j < P) offsets[j] = base + ex[i];
+		}
+	}
+
 	// phase A: per-chunk (4096) sums of the gathered counts
 	__global__ void __launch_bounds__(256) offsets_reduce_kernel(const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ order,
 	                                                            int P, uint32_t* __restrict__ block_sums)
@@ -288,8 +358,8 @@ namespace fdgs
 		if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 	}
 
-	// phase B: one workgroup scans the chunk sums in place (exclusive); grand total -> block_sums[nblocks]
-	__global__ void __launch_bounds__(256) offsets_scan_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks)
+	// phase B: one workgroup scans the chunk sums in place (exclusive); grand total -> *total_out
+	__global__ void __launch_bounds__(256) offsets_scan_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total_out)
 	{
 		__shared__ uint32_t smem[16];
 		__shared__ uint32_t total_s, carry_s;
@@ -306,7 +376,7 @@ namespace fdgs
 			if (threadIdx.x == 0) carry_s = carry + total_s;
 			__syncthreads();
 		}
-		if (threadIdx.x == 0) block_sums[nblocks] = carry_s;
+		if (threadIdx.x == 0) *total_out = carry_s;
 	}
 
 	// phase C: final exclusive offsets
@@ -333,9 +403,18 @@ namespace fdgs
 	                               uint32_t* offsets, uint32_t* block_sums, hipStream_t stream)
 	{
 		const int nblocks = div_up(P, SCAN_CHUNK);
-		hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, tiles_touched, order, P, block_sums);
-		hipLaunchKernelGGL(offsets_scan_sums_kernel, dim3(1), dim3(256), 0, stream, block_sums, nblocks);
-		hipLaunchKernelGGL(offsets_final_kernel, dim3(nblocks), dim3(256), 0, stream, tiles_touched, order, P, block_sums, offsets);
+		uint32_t* total = scan_total_ptr(block_sums, P);
+		if (nblocks <= LOOKBACK_MAX_BLOCKS)
+		{
+			// the state words were cleared by the forward's first kernel (preprocess_fwd.hip)
+			hipLaunchKernelGGL(offsets_lookback_kernel, dim3(nblocks), dim3(256), 0, stream, tiles_touched, order, P,
+			                   reinterpret_cast<unsigned long long*>(block_sums), total, offsets);
+			return hipGetLastError();
+		}
+		uint32_t* sums = block_sums;   // fallback: reduce / scan / final; the chunk sums reuse the front of the state area
+		hipLaunchKernelGGL(offsets_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, tiles_touched, order, P, sums);
+		hipLaunchKernelGGL(offsets_scan_sums_kernel, dim3(1), dim3(256), 0, stream, sums, nblocks, total);
+		hipLaunchKernelGGL(offsets_final_kernel, dim3(nblocks), dim3(256), 0, stream, tiles_touched, order, P, sums, offsets);
 		return hipGetLastError();
 	}
 

@@ -208,7 +208,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		// num_rendered read-back (the one host sync of the forward pass)
 		static thread_local uint32_t* pinned = nullptr;
 		if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault), "hipHostMalloc");
-		HIP_TRY(hipMemcpyAsync(pinned, block_sums + div_up(P, SCAN_CHUNK), 4, hipMemcpyDeviceToHost, stream), "num_rendered copy");
+		HIP_TRY(hipMemcpyAsync(pinned, scan_total_ptr(block_sums, P), 4, hipMemcpyDeviceToHost, stream), "num_rendered copy");
 		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
 		R = (int)*pinned;
 		if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");

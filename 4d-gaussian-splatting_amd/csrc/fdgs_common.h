@@ -53,7 +53,7 @@ namespace fdgs
 		for (int i = 0; i < 2; i++) { L.sort_key[i] = o; o = align_up(o + p * 4); }
 		for (int i = 0; i < 2; i++) { L.sort_val[i] = o; o = align_up(o + p * 4); }
 		L.offsets = o; o = align_up(o + p * 4);
-		L.scan_block = o; o = align_up(o + ((size_t)div_up((int)p, SCAN_CHUNK) + 2) * 4);
+		L.scan_block = o; o = align_up(o + ((size_t)div_up((int)p, SCAN_CHUNK) + 2) * 8);   // 64-bit look-back words + the total
 		L.hist = o; o = align_up(o + (size_t)RADIX * (sort_blocks((int)p) + 1) * 4);
 		L.total = o;
 		return L;
@@ -110,7 +110,11 @@ namespace fdgs
 	hipError_t radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int n, int bit_lo, int bit_hi,
 	                            uint32_t* hist, hipStream_t stream, int* result);
 
-	// offsets[j] = exclusive prefix sum of tiles_touched[order[j]]; total written to block_sums[nblocks].
+	// offsets[j] = exclusive prefix sum of tiles_touched[order[j]]; total (= R) written to scan_total_ptr(block_sums, P).
+	// block_sums: one 64-bit look-back word per 1024-element chunk, zero on entry, then the 32-bit total.
+	constexpr int LOOKBACK_MAX_BLOCKS = 2048;   // all workgroups of the single-pass scan must be resident at once
+	static inline uint32_t* scan_total_ptr(uint32_t* block_sums, int P) { return block_sums + 2 * (size_t)div_up(P, SCAN_CHUNK); }
+	static inline int scan_state_words(int P) { return div_up(P, SCAN_CHUNK) <= LOOKBACK_MAX_BLOCKS ? div_up(P, SCAN_CHUNK) : 0; }
 	hipError_t launch_offsets_scan(const uint32_t* tiles_touched, const uint32_t* order, int P,
 	                               uint32_t* offsets, uint32_t* block_sums, hipStream_t stream);
 

@@ -37,6 +37,7 @@ namespace fdgs
 		// outputs
 		int32_t* radii; float* out_means3D; float* covs_com;
 		float4* records; float* depths; float* cov3D; uint32_t* tiles_touched; ushort4* rect; uint8_t* clamped;
+		unsigned long long* scan_state; int scan_state_words;   // look-back words of the offset scan, cleared here (binning.hip)
 		uint32_t* sort_key; uint32_t* sort_val;
 	};
 
@@ -184,6 +185,7 @@ namespace fdgs
 	{
 		// every lane stays until the end: the SH blocks are staged cooperatively per wave
 		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
+		if (tid_g < a.scan_state_words) a.scan_state[tid_g] = 0ull;   // first kernel of the forward: clears the single-pass scan's words
 		const bool valid = tid_g < a.P;
 		const int idx = valid ? tid_g : a.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
 
@@ -422,6 +424,8 @@ namespace fdgs
 		a.clamped = reinterpret_cast<uint8_t*>(geom + L.clamped);
 		a.sort_key = reinterpret_cast<uint32_t*>(geom + L.sort_key[0]);
 		a.sort_val = reinterpret_cast<uint32_t*>(geom + L.sort_val[0]);
+		a.scan_state = reinterpret_cast<unsigned long long*>(geom + L.scan_block);
+		a.scan_state_words = scan_state_words(s.P);
 		hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();
 	}
