@@ -439,16 +439,23 @@ namespace fdgs
 		__shared__ uint32_t win[EMIT_SLOTS + 1];
 		__shared__ int j0_s;
 		const int s0 = blockIdx.x * EMIT_SLOTS;
-		if (threadIdx.x == 0)
+		if (threadIdx.x < WAVE)
 		{
-			// largest j with offsets[j] <= s0 (offsets is non-decreasing; culled Gaussians sit at the end with offset R)
-			int lo = 0, hi = P - 1;
-			while (lo < hi)
+			// largest j with offsets[j] <= s0 (offsets is non-decreasing; culled Gaussians sit at the end with offset R).
+			// 64-ary search by one wave: 3 dependent loads for 300 k Gaussians instead of 18 for a binary search by one lane.
+			const int lane = threadIdx.x;
+			int lo = 0, n = P;                       // invariant: offsets[lo] <= s0 (offsets[0] = 0), answer in [lo, lo + n)
+			while (n > 1)
 			{
-				const int mid = (lo + hi + 1) >> 1;
-				if (offsets[mid] <= (uint32_t)s0) lo = mid; else hi = mid - 1;
+				const int step = (n + WAVE - 1) / WAVE;
+				const int idx = lo + lane * step;
+				const bool ok = idx < lo + n && offsets[idx] <= (uint32_t)s0;
+				const unsigned long long m = __ballot(ok);   // a prefix of the lanes (monotone), lane 0 always set
+				const int k = 63 - __clzll((long long)m);
+				n = min(step, lo + n - (lo + k * step));
+				lo += k * step;
 			}
-			j0_s = lo;
+			if (lane == 0) j0_s = lo;
 		}
 		__syncthreads();
 		const int j0 = j0_s;
