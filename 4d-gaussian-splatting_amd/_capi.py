@@ -57,7 +57,7 @@ class FdgsBackwardOut(C.Structure):
 
 class FdgsDebugView(C.Structure):
     _fields_ = [("depths", _fp), ("records", _fp), ("cov3D", _fp), ("tiles_touched", _fp), ("clamped", _fp),
-                ("depth_order", _fp), ("point_list", _fp), ("tile_keys", _fp), ("ranges", _fp), ("n_contrib", _fp),
+                ("point_list", _fp), ("ranges", _fp), ("n_contrib", _fp),
                 ("final_T", _fp)]
 
 
@@ -70,7 +70,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_profile_enable", "fdgs_profile_read",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
@@ -99,6 +99,10 @@ def _load():
     lib.fdgs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.POINTER(FdgsDebugView)]
     lib.fdgs_debug_views.restype = C.c_int
+    lib.fdgs_debug_activations.argtypes = [C.c_int32] + [C.c_void_p] * 11
+    lib.fdgs_debug_activations.restype = C.c_int
+    lib.fdgs_debug_tile_sort_limits.argtypes = [C.c_int32, C.c_int32]
+    lib.fdgs_debug_tile_sort_limits.restype = None
     lib.fdgs_profile_enable.argtypes = [C.c_int]
     lib.fdgs_profile_enable.restype = C.c_int
     lib.fdgs_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -172,6 +176,20 @@ def _dev_f32(t, name):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def debug_activations(opacity_raw=None, scales_raw=None, scales_t_raw=None, rotations_raw=None, rotations_r_raw=None):
+    """The activated tensors the kernels derive from raw parameters (fdgs_debug_activations): bit-identical to what
+    preprocess computes in flight with fdgs_scene.raw_params = 1.  Returns a 5-tuple (None where the input was None)."""
+    ins = [opacity_raw, scales_raw, scales_t_raw, rotations_raw, rotations_r_raw]
+    ref = next(t for t in ins if t is not None)
+    ins = [_dev_f32(t, "raw parameter") for t in ins]
+    outs = [None if t is None else torch.empty_like(t) for t in ins]
+    P = int(ref.shape[0])
+    with torch.cuda.device(ref.device):
+        rc = lib.fdgs_debug_activations(P, *[_ptr(t) for t in ins], *[_ptr(t) for t in outs], current_stream_handle(ref.device))
+    _check(rc, "fdgs_debug_activations")
+    return tuple(outs)
 
 
 def current_stream_handle(device):

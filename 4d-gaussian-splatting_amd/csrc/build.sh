@@ -15,7 +15,7 @@ COMMON="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno
 declare -A EXTRA=( [preprocess_fwd]="-ffp-contract=off" [preprocess_bwd]="-ffp-contract=off" [sh_bwd]="-ffp-contract=off" [knn]="-ffp-contract=off" )
 OBJS=()
 PIDS=()
-for src in preprocess_fwd binning blend_fwd blend_bwd preprocess_bwd sh_bwd ssim adam densify knn capi; do
+for src in preprocess_fwd tilebin radix_sort blend_fwd blend_bwd preprocess_bwd sh_bwd ssim adam densify knn capi; do
   obj=build/$src.o
   OBJS+=("$obj")
   if [[ ! -f $obj || $src.hip -nt $obj || fdgs_common.h -nt $obj || blend_common.h -nt $obj || fdgs_math.h -nt $obj || ../../include/fdgs.h -nt $obj ]]; then

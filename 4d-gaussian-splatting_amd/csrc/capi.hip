@@ -93,8 +93,8 @@ namespace
 			if (locked) g_prof_mu.unlock();
 		}
 	};
-	const char* const STAGE_NAMES[FDGS_NUM_STAGES] = { "preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
-		"tile_sort", "tile_ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero", "sh_bwd" };
+	const char* const STAGE_NAMES[FDGS_NUM_STAGES] = { "preprocess_fwd", "tile_count", "tile_scan", "tile_scatter",
+		"tile_sort", "readback", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero", "sh_bwd" };
 }
 
 extern "C" int fdgs_profile_enable(int stage_mask) { g_prof_mask.store((uint32_t)stage_mask); return FDGS_OK; }
@@ -157,12 +157,10 @@ static int check_scene(const fdgs_scene* s)
 
 extern "C" size_t fdgs_geometry_bytes(int32_t P) { return geom_layout(P).total; }
 extern "C" size_t fdgs_image_bytes(int32_t W, int32_t H) { return image_layout(W, H).total; }
-extern "C" size_t fdgs_binning_bytes(int32_t R, int32_t, int32_t) { return bin_layout(R).total; }
+extern "C" size_t fdgs_binning_bytes(int32_t R, int32_t, int32_t) { return bin_layout(R, false).total; }
+extern "C" void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max) { tile_sort_debug_limits(lds_cap, rank_max); }
 extern "C" const char* fdgs_last_error(void) { return g_err; }
 extern "C" int fdgs_version(void) { return FDGS_VERSION; }
-
-// which ping-pong buffer holds the sorted output after `passes` radix passes
-static inline int final_buf(int passes) { return passes & 1; }
 
 extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                                       fdgs_alloc_fn alloc, void* alloc_user, void* stream_v, int32_t* num_rendered)
@@ -189,50 +187,47 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
 	uint32_t* ranges = (uint32_t*)(img + IL.ranges);
 
-	int R = 0;
+	uint32_t* counters = (uint32_t*)(img + IL.tile_counters);
+	uint32_t* ctl = (uint32_t*)(img + IL.bin_ctl);
+	int R = 0, longest = 0;
 	uint32_t* point_list = nullptr;
 	if (P > 0)
 	{
-		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, stream), "preprocess_fwd");
+		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, stream), "preprocess_fwd");
+		const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
+		STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
+		STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, stream), "tile scan");
 
-		uint32_t* dk[2] = { (uint32_t*)(geom + GL.sort_key[0]), (uint32_t*)(geom + GL.sort_key[1]) };
-		uint32_t* dv[2] = { (uint32_t*)(geom + GL.sort_val[0]), (uint32_t*)(geom + GL.sort_val[1]) };
-		int dres = 0;
-		STAGE(FDGS_STAGE_DEPTH_SORT, radix_sort_pairs(dk, dv, P, 0, 32, (uint32_t*)(geom + GL.hist), stream, &dres), "depth sort");
-		const uint32_t* order = dv[dres];
-
-		uint32_t* block_sums = (uint32_t*)(geom + GL.scan_block);
-		STAGE(FDGS_STAGE_OFFSET_SCAN, launch_offsets_scan((const uint32_t*)(geom + GL.tiles_touched), order, P,
-		                          (uint32_t*)(geom + GL.offsets), block_sums, stream), "offset scan");
-
-		// num_rendered read-back (the one host sync of the forward pass)
+		// num_rendered (and the longest tile list) read-back: the one host sync of the forward pass
 		static thread_local uint32_t* pinned = nullptr;
 		if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault), "hipHostMalloc");
-		HIP_TRY(hipMemcpyAsync(pinned, scan_total_ptr(block_sums, P), 4, hipMemcpyDeviceToHost, stream), "num_rendered copy");
+		{
+			StageTimer timer__(FDGS_STAGE_READBACK, stream);
+			HIP_TRY(hipMemcpyAsync(pinned, ctl, 8, hipMemcpyDeviceToHost, stream), "num_rendered copy");
+		}
 		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
-		R = (int)*pinned;
+		R = (int)pinned[0];
+		longest = (int)pinned[1];
 		if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
 	}
 	*num_rendered = R;
 
-	const BinLayout BL = bin_layout(R);
+	const bool big = longest > tile_sort_lds_cap();
+	const BinLayout BL = bin_layout(R, big);
 	char* bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
 	if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
 
 	if (R > 0)
 	{
-		uint32_t* tk[2] = { (uint32_t*)(bin + BL.key[0]), (uint32_t*)(bin + BL.key[1]) };
-		uint32_t* tv[2] = { (uint32_t*)(bin + BL.val[0]), (uint32_t*)(bin + BL.val[1]) };
-		const int dres = final_buf(4);
-		STAGE(FDGS_STAGE_EMIT, launch_emit_instances((const uint32_t*)(geom + GL.sort_val[dres]), (const uint32_t*)(geom + GL.offsets),
-		                            (const uint16_t*)(geom + GL.rect), P, R, gx, tk[0], tv[0], stream), "emit instances");
-		int tres = 0;
-		STAGE(FDGS_STAGE_TILE_SORT, radix_sort_pairs(tk, tv, R, 0, tile_sort_passes(T) * RADIX_BITS, (uint32_t*)(bin + BL.hist), stream, &tres), "tile sort");
-		STAGE(FDGS_STAGE_TILE_RANGES, launch_tile_ranges(tk[tres], R, T, ranges, stream), "tile ranges");
-		point_list = tv[tres];
+		point_list = (uint32_t*)(bin + BL.point_list);
+		uint32_t* pairs = (uint32_t*)(bin + BL.pairs);
+		STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter((const uint16_t*)(geom + GL.rect), (const float*)(geom + GL.depths), P, gx, T,
+		                          counters, pairs, stream), "tile scatter");
+		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, longest, pairs, point_list, ranges, big ? (void*)(bin + BL.big_scratch) : nullptr,
+		                       stream), "tile sort");
 	}
 	else
-		STAGE(FDGS_STAGE_TILE_RANGES, hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
+		STAGE(FDGS_STAGE_TILE_SORT, hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
 
 	// with nothing to blend the kernel still writes background colour / T = 1 everywhere
 	STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, (const float*)(geom + GL.records), point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
@@ -263,16 +258,14 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 		if (s.rot_4d && (!out->dL_dscales_t || !out->dL_drotations_r || !out->dL_dts))
 			return fail(FDGS_ERR_INVALID_ARG, "dL_dscales_t / dL_drotations_r / dL_dts must not be NULL for rot_4d");
 	}
-	const int gx = div_up(W, TILE_X), gy = div_up(H, TILE_Y), T = gx * gy;
 	const int R = in->num_rendered;
 	const GeomLayout GL = geom_layout(P);
 	const ImageLayout IL = image_layout(W, H);
-	const BinLayout BL = bin_layout(R);
+	const BinLayout BL = bin_layout(R, false);   // point_list sits at the front whatever else the forward asked for
 	const char* geom = (const char*)in->geom_buffer;
 	const char* img = (const char*)in->image_buffer;
 	const char* bin = (const char*)in->binning_buffer;
-	const int tres = final_buf(tile_sort_passes(T));
-	const uint32_t* point_list = (const uint32_t*)(bin + BL.val[tres]);
+	const uint32_t* point_list = (const uint32_t*)(bin + BL.point_list);
 
 	// the packed accumulator records of the blend backward start from zero
 	if (!out->grad_accum_clean)
@@ -298,6 +291,18 @@ extern "C" int fdgs_mark_visible(int32_t P, const float* means3D, const float* v
 	return FDGS_OK;
 }
 
+extern "C" int fdgs_debug_activations(int32_t P, const float* opacity_raw, const float* scales_raw, const float* scales_t_raw,
+                                       const float* rotations_raw, const float* rotations_r_raw, float* opacity, float* scales,
+                                       float* scales_t, float* rotations, float* rotations_r, void* stream_v)
+{
+	g_err[0] = 0;
+	if (P < 0) return fail(FDGS_ERR_INVALID_ARG, "P < 0");
+	if (P == 0) return FDGS_OK;
+	HIP_TRY(launch_activations(P, opacity_raw, scales_raw, scales_t_raw, rotations_raw, rotations_r_raw, opacity, scales, scales_t,
+	                           rotations, rotations_r, (hipStream_t)stream_v), "activations");
+	return FDGS_OK;
+}
+
 extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
                                 const void* geom_v, const void* bin_v, const void* img_v, fdgs_debug_view* v)
 {
@@ -305,8 +310,7 @@ extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
 	if (!v || !geom_v || !img_v) return fail(FDGS_ERR_INVALID_ARG, "NULL argument");
 	const GeomLayout GL = geom_layout(P);
 	const ImageLayout IL = image_layout(W, H);
-	const BinLayout BL = bin_layout(R);
-	const int T = div_up(W, TILE_X) * div_up(H, TILE_Y);
+	const BinLayout BL = bin_layout(R, false);
 	const char* geom = (const char*)geom_v;
 	const char* bin = (const char*)bin_v;
 	const char* img = (const char*)img_v;
@@ -315,10 +319,7 @@ extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
 	v->cov3D = (const float*)(geom + GL.cov3D);
 	v->tiles_touched = (const uint32_t*)(geom + GL.tiles_touched);
 	v->clamped = (const uint8_t*)(geom + GL.clamped);
-	v->depth_order = (const uint32_t*)(geom + GL.sort_val[final_buf(4)]);
-	const int tres = final_buf(tile_sort_passes(T));
-	v->point_list = bin ? (const uint32_t*)(bin + BL.val[tres]) : nullptr;
-	v->tile_keys = bin ? (const uint32_t*)(bin + BL.key[tres]) : nullptr;
+	v->point_list = bin ? (const uint32_t*)(bin + BL.point_list) : nullptr;
 	v->ranges = (const uint32_t*)(img + IL.ranges);
 	v->n_contrib = (const uint32_t*)(img + IL.n_contrib);
 	v->final_T = (const float*)(img + IL.final_T);

@@ -4,6 +4,7 @@
 // point of each stage.  Written for gfx950 only (wave64, 256 CUs / 8 XCDs).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stddef.h>
 #include <stdint.h>
 #include "../../include/fdgs.h"
@@ -20,8 +21,7 @@ namespace fdgs
 	static inline int sort_blocks(int n) { return (n + SORT_THREADS * sort_items_for(n) - 1) / (SORT_THREADS * sort_items_for(n)); }
 	constexpr int RADIX_BITS = 8;
 	constexpr int RADIX = 1 << RADIX_BITS;
-	constexpr int SCAN_CHUNK = 4096;
-	constexpr int GRAD_ACC_WORDS = 16;  // packed per-Gaussian gradient accumulator record (64 B = one cache line)    // elements per workgroup in the 3-phase scan
+	constexpr int GRAD_ACC_WORDS = 16;  // packed per-Gaussian gradient accumulator record (64 B = one cache line)
 
 	static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 	static inline int div_up(int a, int b) { return (a + b - 1) / b; }
@@ -33,10 +33,6 @@ namespace fdgs
 	struct GeomLayout
 	{
 		size_t records, depths, cov3D, tiles_touched, rect, clamped;
-		size_t sort_key[2], sort_val[2];   // depth sort ping-pong (keys = depth bits, vals = Gaussian id)
-		size_t offsets;                    // exclusive scan of tiles_touched in depth order
-		size_t scan_block;                 // per-chunk sums of the scan (+1 slot: grand total = R)
-		size_t hist;                       // radix block histograms [RADIX][nblocks] + RADIX digit totals
 		size_t total;
 	};
 	static inline GeomLayout geom_layout(int P)
@@ -50,18 +46,19 @@ namespace fdgs
 		L.tiles_touched = o; o = align_up(o + p * 4);
 		L.rect = o; o = align_up(o + p * 8);
 		L.clamped = o; o = align_up(o + p);
-		for (int i = 0; i < 2; i++) { L.sort_key[i] = o; o = align_up(o + p * 4); }
-		for (int i = 0; i < 2; i++) { L.sort_val[i] = o; o = align_up(o + p * 4); }
-		L.offsets = o; o = align_up(o + p * 4);
-		L.scan_block = o; o = align_up(o + ((size_t)div_up((int)p, SCAN_CHUNK) + 2) * 8);   // 64-bit look-back words + the total
-		L.hist = o; o = align_up(o + (size_t)RADIX * (sort_blocks((int)p) + 1) * 4);
 		L.total = o;
 		return L;
 	}
 
+	// Tile binning (tilebin.hip): one instance counter per tile, padded to whole uint4s
+	static inline size_t bin_counter_words(int T) { return ((size_t)T + 3) & ~(size_t)3; }
+
 	struct ImageLayout
 	{
-		size_t final_T, n_contrib, ranges, total;
+		size_t final_T, n_contrib, ranges;
+		size_t tile_counters;   // [T] instance counts -> exclusive starts -> ends (count / scan / scatter passes)
+		size_t bin_ctl;         // { R, longest tile list } written by the scan, read back by the host
+		size_t total;
 	};
 	static inline ImageLayout image_layout(int W, int H)
 	{
@@ -72,57 +69,50 @@ namespace fdgs
 		L.final_T = o; o = align_up(o + n * 4);
 		L.n_contrib = o; o = align_up(o + n * 4);
 		L.ranges = o; o = align_up(o + t * 8);
+		L.tile_counters = o; o = align_up(o + bin_counter_words((int)t) * 4);
+		L.bin_ctl = o; o = align_up(o + 16);
 		L.total = o;
 		return L;
 	}
 
+	// Binning buffer: the sorted instance list the blend kernels walk, the unsorted (depth bits, id) pairs of the
+	// scatter pass, and -- only when some tile's list is longer than the LDS sort takes -- R keys of global scratch.
 	struct BinLayout
 	{
-		size_t key[2], val[2], hist, total;
+		size_t point_list, pairs, big_scratch, total;
 	};
-	static inline BinLayout bin_layout(int R)
+	static inline BinLayout bin_layout(int R, bool with_big_scratch)
 	{
 		BinLayout L;
 		size_t o = 0;
 		const size_t r = (size_t)(R > 0 ? R : 1);
-		for (int i = 0; i < 2; i++) { L.key[i] = o; o = align_up(o + r * 4); }
-		for (int i = 0; i < 2; i++) { L.val[i] = o; o = align_up(o + r * 4); }
-		L.hist = o; o = align_up(o + (size_t)RADIX * (sort_blocks((int)r) + 1) * 4);
+		L.point_list = o; o = align_up(o + r * 4);
+		L.pairs = o; o = align_up(o + r * 8);
+		L.big_scratch = o;
+		if (with_big_scratch) o = align_up(o + r * 8);
 		L.total = o;
 		return L;
 	}
 
-	// number of tile-id bits the instance sort has to look at, and its pass count
-	static inline int tile_bits(int T)
-	{
-		int b = 1;
-		while ((1 << b) < T) b++;
-		return b;
-	}
-	static inline int tile_sort_passes(int T) { return div_up(tile_bits(T), RADIX_BITS); }
-
 	// ---- stage launchers (each enqueues on `stream`, returns hipError_t) ----
 
-	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, hipStream_t stream);
+	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, hipStream_t stream);
 
-	// Stable LSD radix sort of (key,value) u32 pairs on key bits [bit_lo, bit_hi).
+	// Stable LSD radix sort of (key,value) u32 pairs on key bits [bit_lo, bit_hi) (radix_sort.hip; used by knn.hip).
 	// keys[0]/vals[0] hold the input; *result receives the index (0/1) of the buffers holding the output.
 	hipError_t radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int n, int bit_lo, int bit_hi,
 	                            uint32_t* hist, hipStream_t stream, int* result);
 
-	// offsets[j] = exclusive prefix sum of tiles_touched[order[j]]; total (= R) written to scan_total_ptr(block_sums, P).
-	// block_sums: one 64-bit look-back word per 1024-element chunk, zero on entry, then the 32-bit total.
-	constexpr int LOOKBACK_MAX_BLOCKS = 2048;   // all workgroups of the single-pass scan must be resident at once
-	static inline uint32_t* scan_total_ptr(uint32_t* block_sums, int P) { return block_sums + 2 * (size_t)div_up(P, SCAN_CHUNK); }
-	static inline int scan_state_words(int P) { return div_up(P, SCAN_CHUNK) <= LOOKBACK_MAX_BLOCKS ? div_up(P, SCAN_CHUNK) : 0; }
-	hipError_t launch_offsets_scan(const uint32_t* tiles_touched, const uint32_t* order, int P,
-	                               uint32_t* offsets, uint32_t* block_sums, hipStream_t stream);
-
-	// Emit one (tile id, Gaussian id) instance per covered tile, in depth order.
-	hipError_t launch_emit_instances(const uint32_t* order, const uint32_t* offsets, const uint16_t* rect,
-	                                 int P, int R, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
-
-	hipError_t launch_tile_ranges(const uint32_t* sorted_tile_keys, int R, int T, uint32_t* ranges, hipStream_t stream);
+	// Tile binning (tilebin.hip).  counters: bin_counter_words(T) words, zero on entry of the count pass (cleared by
+	// preprocess_fwd, the forward's first kernel); after the scan they hold every tile list's start, after the
+	// scatter its end.  ctl[0] = R, ctl[1] = longest tile list.
+	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream);
+	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, hipStream_t stream);
+	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs, hipStream_t stream);
+	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
+	                            void* big_scratch, hipStream_t stream);
+	int tile_sort_lds_cap();                                   // lists longer than this need the global scratch
+	void tile_sort_debug_limits(int lds_cap, int rank_max);    // test hook (fdgs_debug_tile_sort_limits); <= 0 restores the default
 
 	hipError_t launch_blend_fwd(const fdgs_scene& s, const fdgs_forward_out& out, const float* records,
 	                            const uint32_t* point_list, const uint32_t* ranges,
@@ -140,4 +130,7 @@ namespace fdgs
 	                                 const char* geom, hipStream_t stream);
 
 	hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
+
+	hipError_t launch_activations(int P, const float* opacity_raw, const float* scales_raw, const float* scales_t_raw, const float* rot_raw,
+	                              const float* rot_r_raw, float* opacity, float* scales, float* scales_t, float* rot, float* rot_r, hipStream_t stream);
 }

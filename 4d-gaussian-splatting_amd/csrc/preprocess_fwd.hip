@@ -12,8 +12,9 @@
 // threads; culled Gaussians are never fetched.  It emits ONE packed 48-byte
 // blend record per Gaussian (position, conic, opacity, colour, depth, flow)
 // instead of four separate arrays, the tile rectangle (so later stages never
-// recompute it), the depth-sort key/value pair, and it writes every output
-// unconditionally so no buffer needs pre-zeroing.
+// recompute it), and it writes every output unconditionally so no buffer needs
+// pre-zeroing; as the forward's first kernel it also clears the tile counters
+// of the binning passes (tilebin.hip).
 //
 // Bit-exactness: radius, rectangle, tile count and depth bits must equal the
 // oracle's exactly, so this file is compiled with FP contraction OFF and follows
@@ -37,8 +38,7 @@ namespace fdgs
 		// outputs
 		int32_t* radii; float* out_means3D; float* covs_com;
 		float4* records; float* depths; float* cov3D; uint32_t* tiles_touched; ushort4* rect; uint8_t* clamped;
-		unsigned long long* scan_state; int scan_state_words;   // look-back words of the offset scan, cleared here (binning.hip)
-		uint32_t* sort_key; uint32_t* sort_val;
+		uint32_t* bin_counters; int bin_counter_words;   // tile instance counters of the binning passes, cleared here (tilebin.hip)
 	};
 
 	__device__ __forceinline__ float3 ld3(const float* p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -185,7 +185,8 @@ namespace fdgs
 	{
 		// every lane stays until the end: the SH blocks are staged cooperatively per wave
 		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
-		if (tid_g < a.scan_state_words) a.scan_state[tid_g] = 0ull;   // first kernel of the forward: clears the single-pass scan's words
+		// first kernel of the forward: clears the tile counters of the binning passes (more cells than Gaussians: stride)
+		for (int c = tid_g; c < a.bin_counter_words; c += gridDim.x * blockDim.x) a.bin_counters[c] = 0u;
 		const bool valid = tid_g < a.P;
 		const int idx = valid ? tid_g : a.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
 
@@ -393,12 +394,9 @@ namespace fdgs
 		a.records[3 * (size_t)idx + 0] = make_float4(pix.x, pix.y, conic.x, conic.y);
 		a.records[3 * (size_t)idx + 1] = make_float4(conic.z, radius > 0 ? opacity : 0.0f, rgb.x, rgb.y);
 		a.records[3 * (size_t)idx + 2] = make_float4(rgb.z, depth, flow.x, flow.y);
-		// depth-sort pair: culled Gaussians sort to the end and emit no instances
-		a.sort_key[idx] = radius > 0 ? __float_as_uint(depth) : 0xFFFFFFFFu;
-		a.sort_val[idx] = (uint32_t)idx;
 	}
 
-	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, hipStream_t stream)
+	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, hipStream_t stream)
 	{
 		const GeomLayout L = geom_layout(s.P);
 		PreArgs a;
@@ -422,10 +420,8 @@ namespace fdgs
 		a.tiles_touched = reinterpret_cast<uint32_t*>(geom + L.tiles_touched);
 		a.rect = reinterpret_cast<ushort4*>(geom + L.rect);
 		a.clamped = reinterpret_cast<uint8_t*>(geom + L.clamped);
-		a.sort_key = reinterpret_cast<uint32_t*>(geom + L.sort_key[0]);
-		a.sort_val = reinterpret_cast<uint32_t*>(geom + L.sort_val[0]);
-		a.scan_state = reinterpret_cast<unsigned long long*>(geom + L.scan_block);
-		a.scan_state_words = scan_state_words(s.P);
+		a.bin_counters = bin_counters;
+		a.bin_counter_words = (int)bin_counter_words(a.grid_x * a.grid_y);
 		hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();
 	}
@@ -441,6 +437,35 @@ namespace fdgs
 	hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream)
 	{
 		hipLaunchKernelGGL(mark_visible_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+		return hipGetLastError();
+	}
+
+	// Parity-test introspection (fdgs_debug_activations): the activated tensors preprocess derives from RAW parameters
+	// when fdgs_scene.raw_params != 0, produced by the very same device functions in the same translation unit
+	// (same compiler flags), so they are bit-identical to what the kernels above and preprocess_bwd compute in flight.
+	__global__ void activations_kernel(int P, const float* __restrict__ opacity_raw, const float* __restrict__ scales_raw,
+	                                   const float* __restrict__ scales_t_raw, const float* __restrict__ rot_raw,
+	                                   const float* __restrict__ rot_r_raw, float* __restrict__ opacity, float* __restrict__ scales,
+	                                   float* __restrict__ scales_t, float* __restrict__ rot, float* __restrict__ rot_r)
+	{
+		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= P) return;
+		float unused;
+		if (opacity_raw && opacity) opacity[idx] = act_sigmoid(opacity_raw[idx]);
+		if (scales_raw && scales)
+		{
+			const float3 sc = ld3(scales_raw, idx);
+			scales[3 * (size_t)idx + 0] = expf(sc.x); scales[3 * (size_t)idx + 1] = expf(sc.y); scales[3 * (size_t)idx + 2] = expf(sc.z);
+		}
+		if (scales_t_raw && scales_t) scales_t[idx] = expf(scales_t_raw[idx]);
+		if (rot_raw && rot) reinterpret_cast<float4*>(rot)[idx] = act_normalize(reinterpret_cast<const float4*>(rot_raw)[idx], &unused);
+		if (rot_r_raw && rot_r) reinterpret_cast<float4*>(rot_r)[idx] = act_normalize(reinterpret_cast<const float4*>(rot_r_raw)[idx], &unused);
+	}
+	hipError_t launch_activations(int P, const float* opacity_raw, const float* scales_raw, const float* scales_t_raw, const float* rot_raw,
+	                              const float* rot_r_raw, float* opacity, float* scales, float* scales_t, float* rot, float* rot_r, hipStream_t stream)
+	{
+		hipLaunchKernelGGL(activations_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, opacity_raw, scales_raw, scales_t_raw,
+		                   rot_raw, rot_r_raw, opacity, scales, scales_t, rot, rot_r);
 		return hipGetLastError();
 	}
 }

@@ -193,6 +193,9 @@ class _NativeRasterizer:
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
                                                    _capi.current_stream_handle(dev))
+        if rc != 0 and clean:
+            # a failed call may have left partial sums behind: restore the caller's "all zero on entry" invariant
+            grad_accum.zero_()
         _capi._check(rc, "fdgs_rasterize_backward")
         del keep
         return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],

@@ -44,12 +44,12 @@ ALGO_BYTES = {
     # BASELINE.md's preprocess-bwd figure (68 + 24 M + 150) P_v + cov2D-bwd 104 P_v, split over our two kernels:
     "sh_bwd": lambda P, Pv, M, R, N, T: (24 * M + 44) * Pv,
     "preprocess_bwd": lambda P, Pv, M, R, N, T: (68 + 150 + 104 + 64 - 44) * Pv,  # incl. the fused cov2D backward + record read
-    # our two-level sort: 4 passes over P pairs + 2 passes over R pairs (reads keys for the histogram, then pairs)
-    "depth_sort": lambda P, Pv, M, R, N, T: 4 * (4 + 8 + 8) * P,
-    "tile_sort": lambda P, Pv, M, R, N, T: 2 * (4 + 8 + 8) * R,
-    "emit_instances": lambda P, Pv, M, R, N, T: 8 * R + 16 * P,
-    "offset_scan": lambda P, Pv, M, R, N, T: 20 * P,
-    "tile_ranges": lambda P, Pv, M, R, N, T: 4 * R + 16 * T,
+    # tile binning (csrc/tilebin.hip): count reads the rectangles, scatter writes one (depth bits, id) pair per instance,
+    # the per-tile local sort reads the pairs and writes point_list + ranges
+    "tile_count": lambda P, Pv, M, R, N, T: 8 * P + 4 * T,
+    "tile_scan": lambda P, Pv, M, R, N, T: 8 * T,
+    "tile_scatter": lambda P, Pv, M, R, N, T: 12 * P + 8 * R + 8 * T,
+    "tile_sort": lambda P, Pv, M, R, N, T: 12 * R + 12 * T,
     "grad_zero": lambda P, Pv, M, R, N, T: 64 * P,
 }
 

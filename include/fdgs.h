@@ -162,8 +162,8 @@ typedef struct fdgs_backward_out
 	                                the call leaves it all zero on exit: the last kernel re-zeroes what it has read */
 } fdgs_backward_out;
 
-/* Forward pass: preprocess -> depth sort -> scan -> instance emission -> tile
- * sort -> tile ranges -> per-tile blend.  *num_rendered receives R.
+/* Forward pass: preprocess -> tile count -> tile scan -> [R read back] -> tile scatter -> per-tile
+ * local sort (+ ranges) -> per-tile blend: 6 kernel launches.  *num_rendered receives R.
  * `stream` is a hipStream_t passed as void* so that this header needs no HIP include. */
 int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                            fdgs_alloc_fn alloc, void* alloc_user, void* stream,
@@ -177,7 +177,8 @@ int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,
 int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present, void* stream);
 
-/* Sizes of the opaque scratch buffers (what the allocator will be asked for). */
+/* Sizes of the opaque scratch buffers (what the allocator will be asked for; the binning buffer grows by 8 bytes per
+ * instance in the rare case that a single tile's list is longer than the LDS sort takes, 4096 entries). */
 size_t fdgs_geometry_bytes(int32_t P);
 size_t fdgs_image_bytes(int32_t W, int32_t H);
 size_t fdgs_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
@@ -191,9 +192,7 @@ typedef struct fdgs_debug_view
 	const float* cov3D;            /* [P,6]                                        */
 	const uint32_t* tiles_touched; /* [P]                                          */
 	const uint8_t* clamped;        /* [P]   bit c set: colour channel c clamped    */
-	const uint32_t* depth_order;   /* [P]   Gaussian ids sorted by depth bits (stable) */
 	const uint32_t* point_list;    /* [R]   Gaussian ids sorted by (tile, depth, id) */
-	const uint32_t* tile_keys;     /* [R]   tile id of each sorted instance        */
 	const uint32_t* ranges;        /* [T,2]                                        */
 	const uint32_t* n_contrib;     /* [H*W]                                        */
 	const float* final_T;          /* [H*W]                                        */
@@ -202,17 +201,30 @@ int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                      fdgs_debug_view* view);
 
+/* Introspection for parity tests of the fused-activation mode (fdgs_scene.raw_params = 1): the activated tensors the
+ * kernels derive from the RAW parameters -- sigmoid(opacity), exp(scales), exp(scales_t), v / max(|v|, 1e-12) for the two
+ * quaternions (scene/gaussian_model.py:179-219) -- computed by the same device functions, bit-identical to the values
+ * preprocess uses in flight.  Any input / output pair may be NULL.  A test feeds them to the oracle, so that the
+ * 1e-4 bar applies to the raw_params path as well. */
+int fdgs_debug_activations(int32_t P, const float* opacity_raw, const float* scales_raw, const float* scales_t_raw,
+                           const float* rotations_raw, const float* rotations_r_raw, float* opacity, float* scales,
+                           float* scales_t, float* rotations, float* rotations_r, void* stream);
+
+/* Test hook: lists longer than `lds_cap` entries take the global-scratch sort, tiles whose most crowded depth bucket
+ * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (4096, 48).  Process-wide. */
+void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);
+
 /* Optional per-stage timing with HIP events recorded on the caller's stream (so the
  * numbers are the kernels' own durations on that stream, not host wall time).
  * Disabled by default; when enabled each stage of forward / backward is bracketed
  * by an event pair (non-blocking).  fdgs_profile_read synchronises the pending
  * events and returns the accumulated milliseconds and the number of samples. */
 #define FDGS_STAGE_PREPROCESS_FWD 0
-#define FDGS_STAGE_DEPTH_SORT 1
-#define FDGS_STAGE_OFFSET_SCAN 2
-#define FDGS_STAGE_EMIT 3
+#define FDGS_STAGE_TILE_COUNT 1
+#define FDGS_STAGE_TILE_SCAN 2
+#define FDGS_STAGE_TILE_SCATTER 3
 #define FDGS_STAGE_TILE_SORT 4
-#define FDGS_STAGE_TILE_RANGES 5
+#define FDGS_STAGE_READBACK 5  /* the 8-byte device-to-host copy of R (device side of the forward's one sync) */
 #define FDGS_STAGE_BLEND_FWD 6
 #define FDGS_STAGE_BLEND_BWD 7
 #define FDGS_STAGE_PREPROCESS_BWD 8

@@ -31,11 +31,11 @@ def test_scratch_sizes_are_monotone_and_aligned():
     from fdgs import _capi
     g1, g2 = _capi.lib.fdgs_geometry_bytes(1000), _capi.lib.fdgs_geometry_bytes(300000)
     assert 0 < g1 < g2 and g1 % 256 == 0 and g2 % 256 == 0
-    assert g2 / 300000 < 160  # ~110 B / Gaussian of scratch
+    assert g2 / 300000 < 100  # 89 B / Gaussian of scratch
     i = _capi.lib.fdgs_image_bytes(1352, 1014)
     assert i % 256 == 0 and i >= 1352 * 1014 * 8
     b = _capi.lib.fdgs_binning_bytes(3_000_000, 1352, 1014)
-    assert b % 256 == 0 and 16 * 3_000_000 <= b < 24 * 3_000_000
+    assert b % 256 == 0 and 12 * 3_000_000 <= b < 13 * 3_000_000  # point_list 4 B + (depth bits, id) pairs 8 B per instance
 
 
 def test_argument_errors_are_reported_without_touching_the_gpu():

@@ -46,14 +46,11 @@ def _view(buf, ptr, count, dtype):
     return buf[off:off + nbytes].view(dtype)
 
 
-def run_hip(scene, device, grads=None):
-    """Forward (+ optional backward) of the HIP product through the C ABI; returns numpy dicts."""
+def collect_forward(res, P, W, H):
+    """numpy dict of every forward output + the introspection views of the opaque buffers (fdgs_debug_views)
+    from the 11-tuple the native forward returns."""
     from fdgs import _capi
-    from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
-    sc = scene_to_device(scene, device)
-    res = _C.rasterize_gaussians(*native_args_fwd(sc))
     (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = res
-    P, W, H = int(sc["means3D"].shape[0]), int(sc["W"]), int(sc["H"])
     v = _capi.FdgsDebugView()
     rc = _capi.lib.fdgs_debug_views(P, W, H, R, _capi._ptr(geom), _capi._ptr(binb), _capi._ptr(img), C.byref(v))
     assert rc == 0, _capi.last_error()
@@ -69,9 +66,7 @@ def run_hip(scene, device, grads=None):
         "cov3D": _view(geom, v.cov3D, P * 6, torch.float32).reshape(P, 6).cpu().numpy(),
         "tiles_touched": _view(geom, v.tiles_touched, P, torch.int32).cpu().numpy().astype(np.uint32),
         "clamped_bits": _view(geom, v.clamped, P, torch.uint8).cpu().numpy(),
-        "depth_order": _view(geom, v.depth_order, P, torch.int32).cpu().numpy().astype(np.uint32),
         "point_list": _view(binb, v.point_list, R, torch.int32).cpu().numpy().astype(np.uint32),
-        "tile_keys": _view(binb, v.tile_keys, R, torch.int32).cpu().numpy().astype(np.uint32),
         "ranges": _view(img, v.ranges, ntiles * 2, torch.int32).reshape(ntiles, 2).cpu().numpy().astype(np.uint32),
         "n_contrib": _view(img, v.n_contrib, W * H, torch.int32).reshape(H, W).cpu().numpy().astype(np.uint32),
         "final_T": _view(img, v.final_T, W * H, torch.float32).reshape(H, W).cpu().numpy(),
@@ -80,6 +75,20 @@ def run_hip(scene, device, grads=None):
         "rgb": rec[:, 6:9].copy(), "rec_depth": rec[:, 9].copy(), "rec_flow": rec[:, 10:12].copy(),
     }
     out["clamped"] = np.stack([(out["clamped_bits"] >> i) & 1 for i in range(3)], axis=1).astype(np.uint8)
+    # the tile of sorted instance s is the tile whose range contains s (check_forward compares the ranges themselves too)
+    rg = out["ranges"].astype(np.int64)
+    out["tile_keys"] = np.repeat(np.arange(ntiles, dtype=np.uint32), (rg[:, 1] - rg[:, 0]))
+    return out
+
+
+def run_hip(scene, device, grads=None):
+    """Forward (+ optional backward) of the HIP product through the C ABI; returns numpy dicts."""
+    from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
+    sc = scene_to_device(scene, device)
+    res = _C.rasterize_gaussians(*native_args_fwd(sc))
+    (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = res
+    P, W, H = int(sc["means3D"].shape[0]), int(sc["W"]), int(sc["H"])
+    out = collect_forward(res, P, W, H)
     gout = None
     if grads is not None:
         e = torch.Tensor([])
@@ -114,11 +123,16 @@ def run_oracle(scene, grads=None, kind="port"):
     return out, gout
 
 
-def check_forward(hip, ref, label="", precomp_cov=False, precomp_colors=False):
+def check_forward(hip, ref, label="", precomp_cov=False, precomp_colors=False, max_border=1e-3):
     """Bit-exact integer / key indexing, 1e-4 pixels (away from flagged threshold cliffs). Returns a report dict."""
     rep = {}
+    # Gaussians whose temporal marginal sits within 1e-5 (relative) of the 0.05 cull threshold: the two expf
+    # implementations may decide differently.  Everything below assumes they did not -- say so if they did.
     bg = ref["border_g"].astype(bool)
-    assert bg.sum() == 0, "%s: scene has %d Gaussians on the temporal-cull cliff; pick another seed" % (label, bg.sum())
+    rep["cull_cliff_gaussians"] = int(bg.sum())
+    if bg.any() and not np.array_equal(hip["radii"][bg] > 0, ref["radii"][bg] > 0):
+        raise AssertionError("%s: %d Gaussians sit on the temporal-cull cliff and the kernel decided differently from "
+                             "the oracle; pick another seed / timestamp" % (label, int(bg.sum())))
     vis = ref["radii"] > 0
     np.testing.assert_array_equal(hip["radii"], ref["radii"], err_msg=label + " radii")
     np.testing.assert_array_equal(hip["tiles_touched"], ref["tiles_touched"], err_msg=label + " tiles_touched")
@@ -145,7 +159,8 @@ def check_forward(hip, ref, label="", precomp_cov=False, precomp_colors=False):
         np.testing.assert_array_equal(hip["clamped"][vis], ref["clamped"][vis], err_msg=label + " clamped")
     border = ref["border"].astype(bool)
     rep["border_frac"] = float(border.mean())
-    assert rep["border_frac"] < 2e-3, "%s: too many cliff pixels %g" % (label, rep["border_frac"])
+    bound = max(max_border, 3.0 / border.size)   # tiny images: allow a handful of pixels
+    assert rep["border_frac"] < bound, "%s: too many cliff pixels %g (bound %g)" % (label, rep["border_frac"], bound)
     ok = ~border
     nc_diff = int((hip["n_contrib"][ok] != ref["n_contrib"][ok]).sum())
     rep["n_contrib_diff_nonborder"] = nc_diff

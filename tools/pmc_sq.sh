@@ -12,7 +12,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for fn in glob.glob("$OUT/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(fn)):
         k = r["Kernel_Name"].split("(")[0]
-        if not any(t in k for t in ("blend", "preprocess", "ssim", "sh_bwd")): continue
+        if not any(t in k for t in ("blend", "preprocess", "ssim", "sh_bwd", "tile_")): continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 for k in sorted(tot):
     print(k)
