@@ -280,16 +280,22 @@ namespace fdgs
 			}
 	}
 
+	constexpr int TS_SUB = 4;                           // linear sub-buckets inside every splitter interval
+	constexpr int TS_NBK = (TS_NS + 1) * TS_SUB;        // 260 buckets
+	constexpr int TS_PAD = 128;                         // sentinel keys behind the list (>= the largest rank_max)
+
 	template <int THREADS, int ITEMS>
 	__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
 	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
 	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
 	                                                           int lds_cap, int rank_max)
 	{
-		extern __shared__ u64 s_a[];               // lds_cap keys
-		__shared__ u64 s_split[TS_NS];
-		__shared__ uint32_t s_hist[TS_NS + 2];     // bucket sizes -> starts; [65] = n
-		__shared__ uint32_t s_maxb;
+		// LDS: lds_cap + TS_PAD depth keys, then lds_cap ids, in bucket order (8 lds_cap + 4 TS_PAD bytes); the same
+		// bytes hold the 64-bit keys of the bitonic fall-back and, at the end, the ids in final order
+		extern __shared__ uint32_t s_dyn[];
+		__shared__ uint32_t s_split[TS_NS];
+		__shared__ uint32_t s_hist[TS_NBK + 4];    // bucket sizes -> starts; [TS_NBK] = n
+		__shared__ uint32_t s_flag[2];             // largest bucket, depth ties seen
 		constexpr int GROUPS = ITEMS / TS_G;
 		const int tid = threadIdx.x, lane = tid & 63;
 		// after the scatter pass a tile's counter holds the END of its list = the start of the next tile's
@@ -318,15 +324,17 @@ namespace fdgs
 			for (int i = tid; i < n; i += THREADS) point_list[start + i] = (uint32_t)S[i];
 			return;
 		}
+		uint32_t* s_key = s_dyn;                          // [lds_cap + TS_PAD]
+		uint32_t* s_id = s_dyn + lds_cap + TS_PAD;        // [lds_cap]
 
-		// keys: registers (TS_G at a time side by side) + a copy in LDS in list order
+		// the list: TS_G (depth bits, id) pairs side by side per thread and group
 		const int ngroups = (n + THREADS * TS_G - 1) / (THREADS * TS_G);
-		u64 e[ITEMS];
+		uint32_t key[ITEMS], id[ITEMS];
 #pragma unroll
 		for (int g = 0; g < GROUPS; g++)
 		{
 #pragma unroll
-			for (int u = 0; u < TS_G; u++) e[g * TS_G + u] = ~0ull;
+			for (int u = 0; u < TS_G; u++) { key[g * TS_G + u] = 0xFFFFFFFFu; id[g * TS_G + u] = 0xFFFFFFFFu; }
 			if (g < ngroups)
 			{
 #pragma unroll
@@ -336,35 +344,34 @@ namespace fdgs
 					if (idx < n)
 					{
 						const uint2 p = pairs[start + idx];
-						e[g * TS_G + u] = ((u64)p.x << 32) | p.y;
-						s_a[idx] = e[g * TS_G + u];
+						key[g * TS_G + u] = p.x;
+						id[g * TS_G + u] = p.y;
 					}
 				}
 			}
 		}
-		for (int i = tid; i < TS_NS + 2; i += THREADS) s_hist[i] = 0u;
-		__syncthreads();
-
+		for (int i = tid; i < TS_NBK + 4; i += THREADS) s_hist[i] = 0u;
+		if (tid < 2) s_flag[tid] = 0u;
 		const bool direct = n <= TS_DIRECT;   // one bucket
 		if (!direct && tid < WAVE)
 		{
-			// 64 regular samples, sorted across the lanes of wave 0
-			u64 v = s_a[(int)(((long long)lane * n) >> 6)];
+			// the depth bits of 64 regularly spaced entries, sorted across the lanes of wave 0: the splitters
+			uint32_t v = pairs[start + (uint32_t)(((long long)lane * n) >> 6)].x;
 #pragma unroll
 			for (int k = 2; k <= WAVE; k <<= 1)
 #pragma unroll
 				for (int j = k >> 1; j > 0; j >>= 1)
 				{
-					const u64 o = shfl_xor_u64(v, j);
+					const uint32_t o = (uint32_t)__shfl_xor((int)v, j);
 					const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-					v = keep_min ? (o < v ? o : v) : (o > v ? o : v);
+					v = keep_min ? min(v, o) : max(v, o);
 				}
 			s_split[lane] = v;
 		}
 		__syncthreads();
 
-		// bucket = number of splitters < key (lower bound over the 64 sorted splitters, TS_G searches side by side);
-		// br = bucket << 16 | arrival index inside the bucket
+		// bucket = (number of splitters < depth bits) * TS_SUB + linear position inside the splitter interval: monotone in
+		// the depth bits, so equal depths share a bucket; br = bucket << 16 | arrival index inside the bucket
 		uint32_t br[ITEMS];
 #pragma unroll
 		for (int g = 0; g < GROUPS; g++)
@@ -378,15 +385,25 @@ namespace fdgs
 				for (int u = 0; u < TS_G; u++) b[u] = 0;
 				if (!direct)
 				{
-					const u64 last = s_split[TS_NS - 1];
+					const uint32_t last = s_split[TS_NS - 1];
 #pragma unroll
 					for (int step = TS_NS / 2; step > 0; step >>= 1)
 #pragma unroll
 						for (int u = 0; u < TS_G; u++)
-							if (s_split[b[u] + step - 1] < e[g * TS_G + u]) b[u] += step;
+							if (s_split[b[u] + step - 1] < key[g * TS_G + u]) b[u] += step;
 #pragma unroll
 					for (int u = 0; u < TS_G; u++)
-						if (last < e[g * TS_G + u]) b[u] = TS_NS;
+					{
+						const uint32_t k = key[g * TS_G + u];
+						if (last < k) b[u] = TS_NS;
+						uint32_t sub = 0;
+						if (b[u] > 0 && b[u] < TS_NS)
+						{
+							const uint32_t lo = s_split[b[u] - 1], hi = s_split[b[u]];   // lo < k <= hi
+							sub = min((uint32_t)TS_SUB - 1u, (uint32_t)((float)(k - lo - 1u) * ((float)TS_SUB * __builtin_amdgcn_rcpf((float)(hi - lo)))));
+						}
+						b[u] = b[u] * TS_SUB + (int)sub;
+					}
 				}
 #pragma unroll
 				for (int u = 0; u < TS_G; u++)
@@ -396,9 +413,14 @@ namespace fdgs
 		__syncthreads();
 		if (tid < WAVE)
 		{
-			// exclusive scan of the 65 bucket sizes by wave 0; the largest bucket
-			const uint32_t c = s_hist[lane], c64 = s_hist[TS_NS];
-			uint32_t incl = c, mb = c;
+			// exclusive scan of the bucket sizes by wave 0 (lane = splitter interval, TS_SUB sizes each); the largest bucket
+			uint32_t c[TS_SUB + 1], sum = 0, mb = 0;
+#pragma unroll
+			for (int q = 0; q < TS_SUB; q++) { c[q] = s_hist[lane * TS_SUB + q]; sum += c[q]; mb = max(mb, c[q]); }
+			uint32_t tail[TS_SUB];
+#pragma unroll
+			for (int q = 0; q < TS_SUB; q++) { tail[q] = s_hist[TS_NS * TS_SUB + q]; mb = max(mb, tail[q]); }
+			uint32_t incl = sum;
 #pragma unroll
 			for (int o = 1; o < WAVE; o <<= 1)
 			{
@@ -406,19 +428,43 @@ namespace fdgs
 				if (lane >= o) incl += t;
 				mb = max(mb, (uint32_t)__shfl_xor((int)mb, o));
 			}
-			s_hist[lane] = incl - c;
-			if (lane == WAVE - 1) { s_hist[TS_NS] = incl; s_hist[TS_NS + 1] = (uint32_t)n; s_maxb = max(mb, c64); }
+			uint32_t run = incl - sum;
+#pragma unroll
+			for (int q = 0; q < TS_SUB; q++) { s_hist[lane * TS_SUB + q] = run; run += c[q]; }
+			if (lane == WAVE - 1)
+			{
+#pragma unroll
+				for (int q = 0; q < TS_SUB; q++) { s_hist[TS_NS * TS_SUB + q] = run; run += tail[q]; }
+				s_hist[TS_NBK] = (uint32_t)n;
+				s_flag[0] = mb;
+			}
 		}
 		__syncthreads();
 
-		if ((int)s_maxb > rank_max && !direct)
+		if ((int)s_flag[0] > rank_max && !direct)
 		{
-			// still a crowded bucket: bitonic sort of the whole list in LDS (s_a holds the keys in list order)
+			// a crowded bucket (a pile of equal / nearly equal depths): bitonic sort of the 64-bit keys in LDS
+			u64* s_a = reinterpret_cast<u64*>(s_dyn);
+#pragma unroll
+			for (int g = 0; g < GROUPS; g++)
+			{
+				if (g < ngroups)
+				{
+#pragma unroll
+					for (int u = 0; u < TS_G; u++)
+					{
+						const int idx = (g * TS_G + u) * THREADS + tid;
+						if (idx < n) s_a[idx] = ((u64)key[g * TS_G + u] << 32) | id[g * TS_G + u];
+					}
+				}
+			}
+			__syncthreads();
 			bitonic_sort<THREADS>(s_a, n);
 			for (int i = tid; i < n; i += THREADS) point_list[start + i] = (uint32_t)s_a[i];
 			return;
 		}
 
+		// keys / ids into LDS in bucket order; TS_PAD sentinels behind the list
 #pragma unroll
 		for (int g = 0; g < GROUPS; g++)
 		{
@@ -426,11 +472,19 @@ namespace fdgs
 			{
 #pragma unroll
 				for (int u = 0; u < TS_G; u++)
-					if ((g * TS_G + u) * THREADS + tid < n) s_a[s_hist[br[g * TS_G + u] >> 16] + (br[g * TS_G + u] & 0xFFFFu)] = e[g * TS_G + u];
+					if ((g * TS_G + u) * THREADS + tid < n)
+					{
+						const uint32_t pos = s_hist[br[g * TS_G + u] >> 16] + (br[g * TS_G + u] & 0xFFFFu);
+						s_key[pos] = key[g * TS_G + u];
+						s_id[pos] = id[g * TS_G + u];
+					}
 			}
 		}
+		for (int i = tid; i < TS_PAD; i += THREADS) s_key[n + i] = 0xFFFFFFFFu;
 		__syncthreads();
-		// final position = start of the bucket + number of smaller keys in it; TS_G keys walk their buckets side by side
+		// Final position = start of the bucket + number of smaller keys in it.  TS_G keys walk their buckets side by side;
+		// a key whose bucket is shorter than its neighbours' keeps reading: whatever follows its bucket has larger depth
+		// bits (later bucket) or is a sentinel, and counts neither as smaller nor as equal.
 		uint32_t fin[ITEMS];
 #pragma unroll
 		for (int g = 0; g < GROUPS; g++)
@@ -439,32 +493,46 @@ namespace fdgs
 			for (int u = 0; u < TS_G; u++) fin[g * TS_G + u] = 0xFFFFFFFFu;
 			if (g < ngroups)
 			{
-				uint32_t bs[TS_G], len[TS_G], rank[TS_G], maxlen = 0;
+				uint32_t bs[TS_G], lt[TS_G], eq[TS_G], maxlen = 0;
 #pragma unroll
 				for (int u = 0; u < TS_G; u++)
 				{
 					const uint32_t b = br[g * TS_G + u] >> 16;
 					const bool valid = (g * TS_G + u) * THREADS + tid < n;
-					bs[u] = s_hist[b];
-					len[u] = valid ? s_hist[b + 1] - bs[u] : 0u;
-					rank[u] = 0;
-					maxlen = max(maxlen, len[u]);
+					bs[u] = valid ? s_hist[b] : (uint32_t)n;      // invalid slots read sentinels only
+					const uint32_t len = valid ? s_hist[b + 1] - bs[u] : 0u;
+					lt[u] = 0; eq[u] = 0;
+					maxlen = max(maxlen, len);
 				}
 				for (uint32_t k = 0; k < maxlen; k++)
 				{
 #pragma unroll
 					for (int u = 0; u < TS_G; u++)
-						if (k < len[u]) rank[u] += (s_a[bs[u] + k] < e[g * TS_G + u]) ? 1u : 0u;
+					{
+						const uint32_t kj = s_key[bs[u] + k];
+						lt[u] += (kj < key[g * TS_G + u]) ? 1u : 0u;
+						eq[u] += (kj == key[g * TS_G + u]) ? 1u : 0u;
+					}
 				}
 #pragma unroll
 				for (int u = 0; u < TS_G; u++)
-					if (len[u] != 0u) fin[g * TS_G + u] = bs[u] + rank[u];
+				{
+					const bool valid = (g * TS_G + u) * THREADS + tid < n;
+					if (valid && eq[u] > 1u)
+					{
+						// equal depth bits: the Gaussian id decides (the reference's stable sort over id-ordered input)
+						const uint32_t b = br[g * TS_G + u] >> 16;
+						const uint32_t be = s_hist[b + 1];
+						for (uint32_t j = bs[u]; j < be; j++)
+							lt[u] += (s_key[j] == key[g * TS_G + u] && s_id[j] < id[g * TS_G + u]) ? 1u : 0u;
+					}
+					if (valid) fin[g * TS_G + u] = bs[u] + lt[u];
+				}
 			}
 		}
-		// ids through LDS in final order, so that point_list is written with contiguous stores (a scattered 4-byte store
-		// costs the CU as much address-processing time as a whole 256-byte one)
+		// ids through LDS in final order, so that point_list is written with contiguous stores
 		__syncthreads();
-		uint32_t* s_out = reinterpret_cast<uint32_t*>(s_a);
+		uint32_t* s_out = s_dyn;
 #pragma unroll
 		for (int g = 0; g < GROUPS; g++)
 		{
@@ -472,7 +540,7 @@ namespace fdgs
 			{
 #pragma unroll
 				for (int u = 0; u < TS_G; u++)
-					if (fin[g * TS_G + u] != 0xFFFFFFFFu) s_out[fin[g * TS_G + u]] = (uint32_t)e[g * TS_G + u];
+					if (fin[g * TS_G + u] != 0xFFFFFFFFu) s_out[fin[g * TS_G + u]] = id[g * TS_G + u];
 			}
 		}
 		__syncthreads();
@@ -525,12 +593,12 @@ namespace fdgs
 	}
 
 	// test hook: lower the list lengths at which the instances hand over, and the crowded-bucket threshold
-	static std::atomic<int> g_small_cap{TS_SMALL}, g_large_cap{TS_LARGE}, g_rank_max{128};
+	static std::atomic<int> g_small_cap{TS_SMALL}, g_large_cap{TS_LARGE}, g_rank_max{96};
 	void tile_sort_debug_limits(int lds_cap, int rank_max)
 	{
 		g_large_cap.store(lds_cap > 0 && lds_cap < TS_LARGE ? lds_cap : TS_LARGE);
 		g_small_cap.store(lds_cap > 0 && lds_cap < TS_SMALL ? lds_cap : TS_SMALL);
-		g_rank_max.store(rank_max > 0 ? rank_max : 128);
+		g_rank_max.store(rank_max > 0 ? min(rank_max, TS_PAD) : 96);
 	}
 	int tile_sort_lds_cap() { return g_large_cap.load(); }
 
@@ -544,12 +612,12 @@ namespace fdgs
 		const int cap = min(small_cap, max(div_up(max_count, 64) * 64, 64));
 		u64* big = reinterpret_cast<u64*>(big_scratch);
 		const bool second = max_count > small_cap;
-		hipLaunchKernelGGL((tile_sort_kernel<TS_SMALL_T, TS_SMALL_ITEMS>), dim3(T), dim3(TS_SMALL_T), (size_t)cap * sizeof(u64), stream, counters, p2,
+		hipLaunchKernelGGL((tile_sort_kernel<TS_SMALL_T, TS_SMALL_ITEMS>), dim3(T), dim3(TS_SMALL_T), (size_t)cap * 8 + TS_PAD * 4, stream, counters, p2,
 		                   point_list, r2, (second && small_cap < large_cap) ? (u64*)nullptr : big, 0, cap, rank_max);
 		if (second && small_cap < large_cap)
 		{
 			const int cap2 = min(large_cap, div_up(max_count, 64) * 64);
-			hipLaunchKernelGGL((tile_sort_kernel<TS_LARGE_T, TS_LARGE_ITEMS>), dim3(T), dim3(TS_LARGE_T), (size_t)cap2 * sizeof(u64), stream, counters, p2,
+			hipLaunchKernelGGL((tile_sort_kernel<TS_LARGE_T, TS_LARGE_ITEMS>), dim3(T), dim3(TS_LARGE_T), (size_t)cap2 * 8 + TS_PAD * 4, stream, counters, p2,
 			                   point_list, r2, big, cap, cap2, rank_max);
 		}
 		return hipGetLastError();
