@@ -26,10 +26,10 @@
 // global counters once per (workgroup, 32 consecutive tiles) -- see the note above tile_bin_lds_kernel.
 //
 // tile_sort, a list of n entries held as 64-bit keys (depth bits << 32 | id):
-//   n <= 4096  one most-significant-digit step on the bits that vary inside THIS tile (1024 buckets between the
-//              list's own min and max depth bits; LDS histogram with returning atomics, scan, scatter into LDS), then
-//              every entry counts the smaller keys of its bucket (buckets hold ~1 entry).  When a bucket is crowded
-//              (many equal or nearly equal depths) the tile falls back to a bitonic sort of the keys in LDS.
+//   n <= 4096  sample sort in LDS (see above tile_sort_kernel): 64 splitters from the list itself, 8 linear sub-buckets
+//              inside every splitter interval, then every entry counts the smaller keys of its bucket; 128 / 256 / 512
+//              threads per tile for lists of up to 1024 / 2048 / 4096 entries.  When a bucket is still crowded (a pile
+//              of equal depths) the tile falls back to a bitonic sort of the 64-bit keys in LDS.
 //   n  > 4096  bitonic sort in global scratch (R keys, requested from the allocator only when such a list exists).
 #include "fdgs_common.h"
 
@@ -237,10 +237,8 @@ namespace fdgs
 	// tile for up to 4096; longer lists are sorted by a bitonic network in global scratch.
 	constexpr int TS_NS = 64;                   // splitters
 	constexpr int TS_G = 4;                     // keys a thread handles side by side (independent LDS chains in flight)
-	constexpr int TS_SMALL_T = 128, TS_SMALL_ITEMS = 8;    // lists of up to 1024 entries: two waves per tile
-	constexpr int TS_LARGE_T = 256, TS_LARGE_ITEMS = 16;   // up to 4096: four waves per tile
-	constexpr int TS_SMALL = TS_SMALL_T * TS_SMALL_ITEMS;
-	constexpr int TS_LARGE = TS_LARGE_T * TS_LARGE_ITEMS;
+	constexpr int TS_ITEMS = 8;                 // keys per thread (two groups of TS_G)
+	constexpr int TS_LARGE = 512 * TS_ITEMS;    // 4096: the longest list sorted in LDS (128 / 256 / 512 threads per tile by length)
 	constexpr int TS_DIRECT = 96;               // lists this short skip the bucketing
 	typedef unsigned long long u64;
 
@@ -280,11 +278,17 @@ namespace fdgs
 			}
 	}
 
-	constexpr int TS_SUB = 4;                           // linear sub-buckets inside every splitter interval
+#ifdef FDGS_TS_TIMELINE   // probe only: cycles between the phases of tile_sort_kernel, summed over the tiles (wave 0, lane 0)
+	__device__ unsigned int* g_tl;   // [T][16] cycles, written without atomics
+#define TL_MARK(k) do { if (tid == 0) { const unsigned long long now__ = __builtin_readcyclecounter(); g_tl[blockIdx.x * 16 + (k)] = (unsigned int)(now__ - tl_prev); tl_prev = now__; } } while (0)
+#else
+#define TL_MARK(k) do { } while (0)
+#endif
+	constexpr int TS_SUB = 8;                           // linear sub-buckets inside every splitter interval
 	constexpr int TS_NBK = (TS_NS + 1) * TS_SUB;        // 260 buckets
 	constexpr int TS_PAD = 128;                         // sentinel keys behind the list (>= the largest rank_max)
 
-	template <int THREADS, int ITEMS>
+	template <int THREADS>
 	__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
 	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
 	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
@@ -296,9 +300,12 @@ namespace fdgs
 		__shared__ uint32_t s_split[TS_NS];
 		__shared__ uint32_t s_hist[TS_NBK + 4];    // bucket sizes -> starts; [TS_NBK] = n
 		__shared__ uint32_t s_flag[2];             // largest bucket, depth ties seen
-		constexpr int GROUPS = ITEMS / TS_G;
+		constexpr int ITEMS = TS_ITEMS, GROUPS = ITEMS / TS_G;
 		const int tid = threadIdx.x, lane = tid & 63;
 		// after the scatter pass a tile's counter holds the END of its list = the start of the next tile's
+#ifdef FDGS_TS_TIMELINE
+		unsigned long long tl_prev = __builtin_readcyclecounter();
+#endif
 		const uint32_t start = blockIdx.x == 0 ? 0u : list_end[blockIdx.x - 1];
 		const uint32_t end = list_end[blockIdx.x];
 		const int n = (int)(end - start);
@@ -327,36 +334,38 @@ namespace fdgs
 		uint32_t* s_key = s_dyn;                          // [lds_cap + TS_PAD]
 		uint32_t* s_id = s_dyn + lds_cap + TS_PAD;        // [lds_cap]
 
-		// the list: TS_G (depth bits, id) pairs side by side per thread and group
-		const int ngroups = (n + THREADS * TS_G - 1) / (THREADS * TS_G);
-		uint32_t key[ITEMS], id[ITEMS];
-#pragma unroll
-		for (int g = 0; g < GROUPS; g++)
-		{
-#pragma unroll
-			for (int u = 0; u < TS_G; u++) { key[g * TS_G + u] = 0xFFFFFFFFu; id[g * TS_G + u] = 0xFFFFFFFFu; }
-			if (g < ngroups)
-			{
-#pragma unroll
-				for (int u = 0; u < TS_G; u++)
-				{
-					const int idx = (g * TS_G + u) * THREADS + tid;
-					if (idx < n)
-					{
-						const uint2 p = pairs[start + idx];
-						key[g * TS_G + u] = p.x;
-						id[g * TS_G + u] = p.y;
-					}
-				}
+		// Per thread: ITEMS (depth bits, id) pairs in registers, in groups of TS_G; a list of n entries uses the first
+		// ngroups groups.  Every phase below walks ALL of a thread's live keys side by side (independent LDS chains in flight).
+#define FOR_ITEMS(...)                                                      \
+		_Pragma("unroll") for (int g_ = 0; g_ < GROUPS; g_++)               \
+			if (g_ < ngroups)                                               \
+			{                                                               \
+				_Pragma("unroll") for (int u_ = 0; u_ < TS_G; u_++)         \
+				{                                                           \
+					const int it = g_ * TS_G + u_;                          \
+					const bool valid = it * THREADS + tid < n;              \
+					(void)valid;                                            \
+					__VA_ARGS__                                             \
+				}                                                           \
 			}
-		}
+		const int ngroups = (n + THREADS * TS_G - 1) / (THREADS * TS_G);
+		const bool direct = n <= TS_DIRECT;   // one bucket
+		uint32_t key[ITEMS], id[ITEMS];
+		uint32_t sample = 0;
+		if (!direct && tid < WAVE) sample = pairs[start + (uint32_t)(((long long)lane * n) >> 6)].x;   // in flight together with the list
+#pragma unroll
+		for (int i = 0; i < ITEMS; i++) { key[i] = 0xFFFFFFFFu; id[i] = 0xFFFFFFFFu; }
+		FOR_ITEMS(if (valid) { const uint2 p = pairs[start + it * THREADS + tid]; key[it] = p.x; id[it] = p.y; })
+#ifdef FDGS_TS_TIMELINE
+		if (key[0] == 0x12345678u) s_flag[0] = 1u;   // forces the wait for the loads before the mark
+#endif
+		TL_MARK(0);
 		for (int i = tid; i < TS_NBK + 4; i += THREADS) s_hist[i] = 0u;
 		if (tid < 2) s_flag[tid] = 0u;
-		const bool direct = n <= TS_DIRECT;   // one bucket
 		if (!direct && tid < WAVE)
 		{
 			// the depth bits of 64 regularly spaced entries, sorted across the lanes of wave 0: the splitters
-			uint32_t v = pairs[start + (uint32_t)(((long long)lane * n) >> 6)].x;
+			uint32_t v = sample;
 #pragma unroll
 			for (int k = 2; k <= WAVE; k <<= 1)
 #pragma unroll
@@ -369,48 +378,36 @@ namespace fdgs
 			s_split[lane] = v;
 		}
 		__syncthreads();
+		TL_MARK(1);
 
 		// bucket = (number of splitters < depth bits) * TS_SUB + linear position inside the splitter interval: monotone in
 		// the depth bits, so equal depths share a bucket; br = bucket << 16 | arrival index inside the bucket
 		uint32_t br[ITEMS];
 #pragma unroll
-		for (int g = 0; g < GROUPS; g++)
+		for (int i = 0; i < ITEMS; i++) br[i] = 0u;
+		if (!direct)
 		{
+			const uint32_t last = s_split[TS_NS - 1];
 #pragma unroll
-			for (int u = 0; u < TS_G; u++) br[g * TS_G + u] = 0u;
-			if (g < ngroups)
+			for (int step = TS_NS / 2; step > 0; step >>= 1)
 			{
-				int b[TS_G];
-#pragma unroll
-				for (int u = 0; u < TS_G; u++) b[u] = 0;
-				if (!direct)
-				{
-					const uint32_t last = s_split[TS_NS - 1];
-#pragma unroll
-					for (int step = TS_NS / 2; step > 0; step >>= 1)
-#pragma unroll
-						for (int u = 0; u < TS_G; u++)
-							if (s_split[b[u] + step - 1] < key[g * TS_G + u]) b[u] += step;
-#pragma unroll
-					for (int u = 0; u < TS_G; u++)
-					{
-						const uint32_t k = key[g * TS_G + u];
-						if (last < k) b[u] = TS_NS;
-						uint32_t sub = 0;
-						if (b[u] > 0 && b[u] < TS_NS)
-						{
-							const uint32_t lo = s_split[b[u] - 1], hi = s_split[b[u]];   // lo < k <= hi
-							sub = min((uint32_t)TS_SUB - 1u, (uint32_t)((float)(k - lo - 1u) * ((float)TS_SUB * __builtin_amdgcn_rcpf((float)(hi - lo)))));
-						}
-						b[u] = b[u] * TS_SUB + (int)sub;
-					}
-				}
-#pragma unroll
-				for (int u = 0; u < TS_G; u++)
-					if ((g * TS_G + u) * THREADS + tid < n) br[g * TS_G + u] = ((uint32_t)b[u] << 16) | atomicAdd(&s_hist[b[u]], 1u);
+				FOR_ITEMS(if (s_split[br[it] + step - 1] < key[it]) br[it] += step;)
 			}
+			FOR_ITEMS(
+				const uint32_t k = key[it];
+				uint32_t b = br[it];
+				if (last < k) b = TS_NS;
+				uint32_t sub = 0;
+				if (b > 0 && b < TS_NS)
+				{
+					const uint32_t lo = s_split[b - 1]; const uint32_t hi = s_split[b];   // lo < k <= hi
+					sub = min((uint32_t)TS_SUB - 1u, (uint32_t)((float)(k - lo - 1u) * ((float)TS_SUB * __builtin_amdgcn_rcpf((float)(hi - lo)))));
+				}
+				br[it] = b * TS_SUB + sub;)
 		}
+		FOR_ITEMS(if (valid) br[it] = (br[it] << 16) | atomicAdd(&s_hist[br[it]], 1u);)
 		__syncthreads();
+		TL_MARK(2);
 		if (tid < WAVE)
 		{
 			// exclusive scan of the bucket sizes by wave 0 (lane = splitter interval, TS_SUB sizes each); the largest bucket
@@ -440,24 +437,13 @@ namespace fdgs
 			}
 		}
 		__syncthreads();
+		TL_MARK(3);
 
 		if ((int)s_flag[0] > rank_max && !direct)
 		{
 			// a crowded bucket (a pile of equal / nearly equal depths): bitonic sort of the 64-bit keys in LDS
 			u64* s_a = reinterpret_cast<u64*>(s_dyn);
-#pragma unroll
-			for (int g = 0; g < GROUPS; g++)
-			{
-				if (g < ngroups)
-				{
-#pragma unroll
-					for (int u = 0; u < TS_G; u++)
-					{
-						const int idx = (g * TS_G + u) * THREADS + tid;
-						if (idx < n) s_a[idx] = ((u64)key[g * TS_G + u] << 32) | id[g * TS_G + u];
-					}
-				}
-			}
+			FOR_ITEMS(if (valid) s_a[it * THREADS + tid] = ((u64)key[it] << 32) | id[it];)
 			__syncthreads();
 			bitonic_sort<THREADS>(s_a, n);
 			for (int i = tid; i < n; i += THREADS) point_list[start + i] = (uint32_t)s_a[i];
@@ -465,86 +451,48 @@ namespace fdgs
 		}
 
 		// keys / ids into LDS in bucket order; TS_PAD sentinels behind the list
-#pragma unroll
-		for (int g = 0; g < GROUPS; g++)
-		{
-			if (g < ngroups)
-			{
-#pragma unroll
-				for (int u = 0; u < TS_G; u++)
-					if ((g * TS_G + u) * THREADS + tid < n)
-					{
-						const uint32_t pos = s_hist[br[g * TS_G + u] >> 16] + (br[g * TS_G + u] & 0xFFFFu);
-						s_key[pos] = key[g * TS_G + u];
-						s_id[pos] = id[g * TS_G + u];
-					}
-			}
-		}
+		FOR_ITEMS(if (valid) { const uint32_t pos = s_hist[br[it] >> 16] + (br[it] & 0xFFFFu); s_key[pos] = key[it]; s_id[pos] = id[it]; })
 		for (int i = tid; i < TS_PAD; i += THREADS) s_key[n + i] = 0xFFFFFFFFu;
 		__syncthreads();
-		// Final position = start of the bucket + number of smaller keys in it.  TS_G keys walk their buckets side by side;
-		// a key whose bucket is shorter than its neighbours' keeps reading: whatever follows its bucket has larger depth
-		// bits (later bucket) or is a sentinel, and counts neither as smaller nor as equal.
+		TL_MARK(4);
+		// Final position = start of the bucket + number of smaller keys in it.  All of a thread's keys walk their buckets
+		// side by side; a key whose bucket is shorter than its neighbours' keeps reading: whatever follows its bucket has
+		// larger depth bits (later bucket) or is a sentinel, and counts neither as smaller nor as equal.  Two instructions per
+		// counter and comparison (compare into VCC, add with carry).
+		uint32_t bs[ITEMS], lt[ITEMS], eq[ITEMS], maxlen = 0;
+#pragma unroll
+		for (int i = 0; i < ITEMS; i++) { bs[i] = (uint32_t)n; lt[i] = 0; eq[i] = 0; }
+		FOR_ITEMS(if (valid) { const uint32_t b = br[it] >> 16; bs[it] = s_hist[b]; maxlen = max(maxlen, s_hist[b + 1] - bs[it]); })
+		for (uint32_t k = 0; k < maxlen; k++)
+		{
+			FOR_ITEMS(
+				const uint32_t kj = s_key[bs[it] + k];
+				asm("v_cmp_lt_u32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+				    "v_cmp_eq_u32 vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+				    : "+v"(lt[it]), "+v"(eq[it]) : "v"(kj), "v"(key[it]) : "vcc");)
+		}
 		uint32_t fin[ITEMS];
 #pragma unroll
-		for (int g = 0; g < GROUPS; g++)
-		{
-#pragma unroll
-			for (int u = 0; u < TS_G; u++) fin[g * TS_G + u] = 0xFFFFFFFFu;
-			if (g < ngroups)
+		for (int i = 0; i < ITEMS; i++) fin[i] = 0xFFFFFFFFu;
+		FOR_ITEMS(
+			if (valid && eq[it] > 1u)
 			{
-				uint32_t bs[TS_G], lt[TS_G], eq[TS_G], maxlen = 0;
-#pragma unroll
-				for (int u = 0; u < TS_G; u++)
-				{
-					const uint32_t b = br[g * TS_G + u] >> 16;
-					const bool valid = (g * TS_G + u) * THREADS + tid < n;
-					bs[u] = valid ? s_hist[b] : (uint32_t)n;      // invalid slots read sentinels only
-					const uint32_t len = valid ? s_hist[b + 1] - bs[u] : 0u;
-					lt[u] = 0; eq[u] = 0;
-					maxlen = max(maxlen, len);
-				}
-				for (uint32_t k = 0; k < maxlen; k++)
-				{
-#pragma unroll
-					for (int u = 0; u < TS_G; u++)
-					{
-						const uint32_t kj = s_key[bs[u] + k];
-						lt[u] += (kj < key[g * TS_G + u]) ? 1u : 0u;
-						eq[u] += (kj == key[g * TS_G + u]) ? 1u : 0u;
-					}
-				}
-#pragma unroll
-				for (int u = 0; u < TS_G; u++)
-				{
-					const bool valid = (g * TS_G + u) * THREADS + tid < n;
-					if (valid && eq[u] > 1u)
-					{
-						// equal depth bits: the Gaussian id decides (the reference's stable sort over id-ordered input)
-						const uint32_t b = br[g * TS_G + u] >> 16;
-						const uint32_t be = s_hist[b + 1];
-						for (uint32_t j = bs[u]; j < be; j++)
-							lt[u] += (s_key[j] == key[g * TS_G + u] && s_id[j] < id[g * TS_G + u]) ? 1u : 0u;
-					}
-					if (valid) fin[g * TS_G + u] = bs[u] + lt[u];
-				}
+				// equal depth bits: the Gaussian id decides (the reference's stable sort over id-ordered input)
+				const uint32_t be = s_hist[(br[it] >> 16) + 1];
+				for (uint32_t j = bs[it]; j < be; j++) lt[it] += (s_key[j] == key[it] && s_id[j] < id[it]) ? 1u : 0u;
 			}
-		}
+			if (valid) fin[it] = bs[it] + lt[it];)
 		// ids through LDS in final order, so that point_list is written with contiguous stores
+		TL_MARK(5);
 		__syncthreads();
+		TL_MARK(6);
 		uint32_t* s_out = s_dyn;
-#pragma unroll
-		for (int g = 0; g < GROUPS; g++)
-		{
-			if (g < ngroups)
-			{
-#pragma unroll
-				for (int u = 0; u < TS_G; u++)
-					if (fin[g * TS_G + u] != 0xFFFFFFFFu) s_out[fin[g * TS_G + u]] = id[g * TS_G + u];
-			}
-		}
+		FOR_ITEMS(if (fin[it] != 0xFFFFFFFFu) s_out[fin[it]] = id[it];)
 		__syncthreads();
+		TL_MARK(7);
 		for (int i = tid; i < n; i += THREADS) point_list[start + i] = s_out[i];
+		TL_MARK(8);
+#undef FOR_ITEMS
 	}
 
 	// ------------------------------------------------------------------------------------------------
@@ -592,33 +540,47 @@ namespace fdgs
 		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, stream);
 	}
 
-	// test hook: lower the list lengths at which the instances hand over, and the crowded-bucket threshold
-	static std::atomic<int> g_small_cap{TS_SMALL}, g_large_cap{TS_LARGE}, g_rank_max{96};
+	// test hook: cap the list length the LDS instances take, and the crowded-bucket threshold
+	static std::atomic<int> g_lds_cap{TS_LARGE}, g_rank_max{96};
 	void tile_sort_debug_limits(int lds_cap, int rank_max)
 	{
-		g_large_cap.store(lds_cap > 0 && lds_cap < TS_LARGE ? lds_cap : TS_LARGE);
-		g_small_cap.store(lds_cap > 0 && lds_cap < TS_SMALL ? lds_cap : TS_SMALL);
+		g_lds_cap.store(lds_cap > 0 && lds_cap < TS_LARGE ? lds_cap : TS_LARGE);
 		g_rank_max.store(rank_max > 0 ? min(rank_max, TS_PAD) : 96);
 	}
-	int tile_sort_lds_cap() { return g_large_cap.load(); }
+	int tile_sort_lds_cap() { return g_lds_cap.load(); }
+
+	template <int THREADS>
+	static void launch_sort_instance(const uint32_t* counters, int T, const uint2* pairs, uint32_t* point_list, uint2* ranges, u64* big,
+	                                 int n_lo, int cap, int rank_max, hipStream_t stream)
+	{
+		hipLaunchKernelGGL((tile_sort_kernel<THREADS>), dim3(T), dim3(THREADS), (size_t)cap * 8 + TS_PAD * 4, stream, counters, pairs, point_list,
+		                   ranges, big, n_lo, cap, rank_max);
+	}
 
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
 	                            void* big_scratch, hipStream_t stream)
 	{
-		const int small_cap = g_small_cap.load(), large_cap = g_large_cap.load(), rank_max = g_rank_max.load();
+		const int lds_cap = g_lds_cap.load(), rank_max = g_rank_max.load();
 		const uint2* p2 = reinterpret_cast<const uint2*>(pairs);
 		uint2* r2 = reinterpret_cast<uint2*>(ranges);
-		// LDS: the longest list this instance takes, in 64-key steps (a short longest list = more tiles in flight per CU)
-		const int cap = min(small_cap, max(div_up(max_count, 64) * 64, 64));
 		u64* big = reinterpret_cast<u64*>(big_scratch);
-		const bool second = max_count > small_cap;
-		hipLaunchKernelGGL((tile_sort_kernel<TS_SMALL_T, TS_SMALL_ITEMS>), dim3(T), dim3(TS_SMALL_T), (size_t)cap * 8 + TS_PAD * 4, stream, counters, p2,
-		                   point_list, r2, (second && small_cap < large_cap) ? (u64*)nullptr : big, 0, cap, rank_max);
-		if (second && small_cap < large_cap)
+		// The main instance takes every tile and is sized by the longest list: 128 threads per tile while no list
+		// exceeds 1024 entries, else 256 (up to 2048 entries; measured at C3, where a quarter of the lists are longer than
+		// 1024: one 256-thread launch 62 us, a 128-thread launch plus a 256-thread launch for the long ones 88 us).  Lists
+		// beyond 2048 are rare: a second launch with 512 threads per tile takes them, and those beyond lds_cap (4096)
+		// go through its global-scratch path.  An instance's LDS is sized by the longest list it takes, in 64-key
+		// steps (a short longest list = more tiles in flight per CU).
+		const int longest_lds = min(max_count, lds_cap);
+		const int c1 = min(128 * TS_ITEMS, lds_cap), c2 = min(256 * TS_ITEMS, lds_cap), c3 = min(512 * TS_ITEMS, lds_cap);
+		const auto lds_keys = [&](int c) { return min(c, max(64, div_up(longest_lds, 64) * 64)); };
+		const bool overflow = max_count > lds_cap;   // somebody has to take the global path
+		if (max_count <= c1 || c2 == c1)
+			launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, stream);
+		else
 		{
-			const int cap2 = min(large_cap, div_up(max_count, 64) * 64);
-			hipLaunchKernelGGL((tile_sort_kernel<TS_LARGE_T, TS_LARGE_ITEMS>), dim3(T), dim3(TS_LARGE_T), (size_t)cap2 * 8 + TS_PAD * 4, stream, counters, p2,
-			                   point_list, r2, big, cap, cap2, rank_max);
+			const bool second = max_count > c2 && c3 > c2;
+			launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, stream);
+			if (second) launch_sort_instance<512>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c2, lds_keys(c3), rank_max, stream);
 		}
 		return hipGetLastError();
 	}

@@ -308,6 +308,21 @@ def test_tile_sort_equal_and_clustered_depths(gpu_device):
     _binning_vs_oracle(scene, gpu_device, "clustered depths")
 
 
+def test_tile_sort_long_lists(gpu_device):
+    """Few tiles, many Gaussians: lists of several thousand entries.  Covers the 256- and 512-thread instances of the LDS
+    sort (lists of up to 2048 / 4096 entries) and, unforced, the global-scratch path for the lists beyond 4096."""
+    seen = []
+    for P, W, H in ((40000, 96, 64), (30000, 128, 96)):
+        scene = synth.make_scene(SC("v", P, W, H, 0, 0, 0.03, 1.0, True, 4, True), seed=15)
+        hip, ref = _binning_vs_oracle(scene, gpu_device, "long lists %dx%d" % (W, H))
+        n = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+        seen += n.tolist()
+        rep = check_forward(hip, ref, "long lists %dx%d" % (W, H))
+        print("long lists %dx%d: longest %d" % (W, H, n.max()), rep)
+    seen = np.array(seen)
+    assert (seen > 4096).any() and ((seen > 2048) & (seen <= 4096)).any() and ((seen > 1024) & (seen <= 2048)).any()
+
+
 def test_binning_many_tiles_direct_path(gpu_device):
     """More tiles than an LDS histogram holds (> 36 864): count / scatter fall back to one global atomic per instance."""
     scene = synth.make_scene(SC("v", 3000, 3104, 3104, 0, 0, 0.02, 1.0, True, 4, True), seed=14)

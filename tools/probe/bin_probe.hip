@@ -20,6 +20,7 @@ int main(int argc, char** argv)
 	const int W = argc > 2 ? atoi(argv[2]) : 1352, H = argc > 3 ? atoi(argv[3]) : 1014;
 	const float mean_r = argc > 4 ? atof(argv[4]) : 18.0f;
 	const int depth_mode = argc > 5 ? atoi(argv[5]) : 0;   // 0 uniform, 1 two surfaces + outliers, 2 all equal
+	const bool quick = argc > 6;                            // only the default variant (for profiling)
 	const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
 	std::mt19937 rng(1);
 	std::uniform_real_distribution<float> U(0.f, 1.f);
@@ -62,6 +63,12 @@ int main(int argc, char** argv)
 			}
 	std::sort(keys.begin(), keys.end());
 
+#ifdef FDGS_TS_TIMELINE
+	unsigned int* d_tl;
+	CK(hipMalloc(&d_tl, (size_t)T * 64));
+	CK(hipMemset(d_tl, 0, (size_t)T * 64));
+	CK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &d_tl, sizeof d_tl));
+#endif
 	hipEvent_t ev[8];
 	for (auto& e : ev) CK(hipEventCreate(&e));
 	const int per_thread = ((T + 1023) / 1024 + 3) / 4 * 4;
@@ -74,6 +81,7 @@ int main(int argc, char** argv)
 			{
 				const int batch = rounds * 1024;
 				if ((caplim == 64 || rank_max == 1) && rounds != 1) continue;
+				if (quick && (rounds != 1 || caplim != 0 || rank_max != 0)) continue;
 				if (caplim == 64 && rank_max == 1) continue;
 				if (rounds > 0 && T > 36 * 1024) continue;
 				tile_sort_debug_limits(caplim, rank_max);
@@ -128,6 +136,17 @@ int main(int argc, char** argv)
 					pos = e;
 				}
 				if (maxc != ctl[1]) bad++;
+#ifdef FDGS_TS_TIMELINE
+				{
+					std::vector<unsigned int> tl((size_t)T * 16);
+					CK(hipMemcpy(tl.data(), d_tl, tl.size() * 4, hipMemcpyDeviceToHost));
+					const char* nm[9] = { "load", "splitters", "search+hist", "scan", "scatter", "rank", "barrier", "out", "store" };
+					printf("   tile_sort cycles per tile (wave 0, last launch):");
+					double tot = 0;
+					for (int k = 0; k < 9; k++) { double a2 = 0; for (int t = 0; t < T; t++) a2 += tl[(size_t)t * 16 + k]; printf(" %s %.0f", nm[k], a2 / T); tot += a2 / T; }
+					printf(" | total %.0f\n", tot);
+				}
+#endif
 				printf("batch %4d lds_cap_limit %4d rank_max %2d | memset %.1f  count %.1f  scan %.1f  scatter %.1f  sort %.1f us | max list %u | %s (%zu bad)\n",
 				       batch, caplim, rank_max, acc[0] / reps * 1e3, acc[1] / reps * 1e3, acc[2] / reps * 1e3, acc[3] / reps * 1e3, acc[4] / reps * 1e3,
 				       ctl[1], bad ? "MISMATCH" : "ok", bad);
