@@ -163,4 +163,36 @@ namespace fdgs
 		                   out.out_color, out.out_flow, out.out_depth, out.out_T, final_T, n_contrib);
 		return hipGetLastError();
 	}
+
+	// Parity-test introspection (fdgs_debug_block_reaches): the block cull of blend_common.h next to the brute force it
+	// must never contradict -- the per-pixel test of the blend kernels above (same arithmetic, same translation unit),
+	// evaluated on every pixel centre of the rectangle.  tuples: [n][10] = x, y, conic xx / xy / yy, opacity, rx0, rx1, ry0,
+	// ry1 (pixel-centre bounds of the block, already clamped to the image).  out: [n][2] = block_reaches, any pixel passes.
+	__global__ void block_reaches_debug_kernel(int n, const float* __restrict__ t, uint8_t* __restrict__ out)
+	{
+		const int i = blockIdx.x * blockDim.x + threadIdx.x;
+		if (i >= n) return;
+		const float* p = t + 10 * (size_t)i;
+		const float4 a = make_float4(p[0], p[1], p[2], p[3]);
+		const float4 b = make_float4(p[4], p[5], 0.f, 0.f);
+		const float rx0 = p[6], rx1 = p[7], ry0 = p[8], ry1 = p[9];
+		out[2 * (size_t)i] = block_reaches(a, b, rx0, rx1, ry0, ry1) ? 1 : 0;
+		bool any = false;
+		for (float py = ry0; py <= ry1; py += 1.0f)
+			for (float px = rx0; px <= rx1; px += 1.0f)
+			{
+				// blend_fwd_kernel's inner loop, one entry
+				const float dx = a.x - px, dy = a.y - py;
+				const float s2 = fmaf(b.x * dy, dy, (a.z * dx) * dx);
+				const float power = fmaf(-0.5f, s2, -((a.w * dx) * dy));
+				const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+				any = any || (!(power > 0.0f) && !(alpha < 1.0f / 255.0f));
+			}
+		out[2 * (size_t)i + 1] = any ? 1 : 0;
+	}
+	hipError_t launch_block_reaches_debug(int n, const float* tuples, uint8_t* out, hipStream_t stream)
+	{
+		hipLaunchKernelGGL(block_reaches_debug_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, tuples, out);
+		return hipGetLastError();
+	}
 }

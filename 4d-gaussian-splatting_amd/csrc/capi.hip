@@ -303,6 +303,15 @@ extern "C" int fdgs_debug_activations(int32_t P, const float* opacity_raw, const
 	return FDGS_OK;
 }
 
+extern "C" int fdgs_debug_block_reaches(int32_t n, const float* tuples, uint8_t* out, void* stream_v)
+{
+	g_err[0] = 0;
+	if (n < 0 || (n > 0 && (!tuples || !out))) return fail(FDGS_ERR_INVALID_ARG, "bad arguments");
+	if (n == 0) return FDGS_OK;
+	HIP_TRY(launch_block_reaches_debug(n, tuples, out, (hipStream_t)stream_v), "block_reaches debug");
+	return FDGS_OK;
+}
+
 extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
                                 const void* geom_v, const void* bin_v, const void* img_v, fdgs_debug_view* v)
 {

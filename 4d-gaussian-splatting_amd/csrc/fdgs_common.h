@@ -131,6 +131,8 @@ namespace fdgs
 
 	hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
 
+	hipError_t launch_block_reaches_debug(int n, const float* tuples, uint8_t* out, hipStream_t stream);
+
 	hipError_t launch_activations(int P, const float* opacity_raw, const float* scales_raw, const float* scales_t_raw, const float* rot_raw,
 	                              const float* rot_r_raw, float* opacity, float* scales, float* scales_t, float* rot, float* rot_r, hipStream_t stream);
 }

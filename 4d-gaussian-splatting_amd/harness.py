@@ -111,16 +111,25 @@ class DensificationStats:
         import ctypes as C
         from . import _capi
         dev = self.xyz_gradient_accum.device
-        P, n = self.xyz_gradient_accum.shape[0], len(results)
+        P = self.xyz_gradient_accum.shape[0]
         radii = [r["radii"].contiguous() for r in results]
         grads = [r["viewspace_grad"].contiguous() for r in results]
-        rp = (C.c_void_p * n)(*[t.data_ptr() for t in radii])
-        gp = (C.c_void_p * n)(*[t.data_ptr() for t in grads])
         tmp = torch.empty((3, P), dtype=torch.float32, device=dev)   # count, pgrad | radii_max
         st = _capi.current_stream_handle(dev)
         with torch.cuda.device(dev):
-            rc = _capi.lib.fdgs_densify_stats_local(P, n, rp, gp, tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), st)
-            _capi._check(rc, "fdgs_densify_stats_local")
+            # the kernel takes at most 16 views per call: larger per-rank batches go in groups, combined like the ranks are
+            GROUP = 16
+            for g0 in range(0, len(results), GROUP):
+                rad, grd = radii[g0:g0 + GROUP], grads[g0:g0 + GROUP]
+                n = len(rad)
+                rp = (C.c_void_p * n)(*[t.data_ptr() for t in rad])
+                gp = (C.c_void_p * n)(*[t.data_ptr() for t in grd])
+                dst = tmp if g0 == 0 else torch.empty_like(tmp)
+                rc = _capi.lib.fdgs_densify_stats_local(P, n, rp, gp, dst[0].data_ptr(), dst[1].data_ptr(), dst[2].data_ptr(), st)
+                _capi._check(rc, "fdgs_densify_stats_local")
+                if g0 > 0:
+                    tmp[:2] += dst[:2]
+                    torch.maximum(tmp[2], dst[2], out=tmp[2])
             if self.world > 1:
                 import torch.distributed as dist
                 dist.all_reduce(tmp[:2], op=dist.ReduceOp.SUM)
@@ -142,7 +151,8 @@ def psnr(img: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
 def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe, bg: torch.Tensor, iterations: int,
           batch_size: int = 4, world_size: int = 1, rank: int = 0, seed: int = 0, lambda_dssim: float = 0.2,
           position_lr_init: float = 1.6e-4, position_lr_final: float = 1.6e-6, position_lr_delay_mult: float = 0.01,
-          position_lr_max_steps: int = 30000, sh_increase_interval: int = 1000, max_sh_degree: Optional[int] = None,
+          position_lr_max_steps: int = 30000, sh_increase_interval: int = 1000, sh_degree_start: Optional[Sequence[int]] = None,
+          white_background: bool = False,
           densify_until_iter: int = 15000, densify_from_iter: int = 500, densification_interval: int = 100,
           opacity_reset_interval: int = 3000, densify_grad_threshold: float = 2e-4, densify_grad_t_threshold: float = 2e-4 / 40,
           thresh_opa_prune: float = 0.005, percent_dense: float = 0.01, cameras_extent: Optional[float] = None,
@@ -152,17 +162,24 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
     each rank renders its FrameShard slice).  Returns the logged history {"iteration", "loss", "psnr"}.
     Densification (train.py:229-244) runs when ``cameras_extent`` is given: every rank takes the same decisions from the
     all-reduced statistics and draws the split samples from a generator seeded with (seed, iteration), so the replicas
-    stay identical without a broadcast.  ``on_densify(model, optimizer, stats, iteration)`` replaces that default."""
+    stay identical without a broadcast.  ``on_densify(model, optimizer, stats, iteration)`` replaces that default.
+    SH schedule (train.py:93-94, gaussian_model.py:253-257): every ``sh_increase_interval`` iterations ``oneupSHdegree()``
+    raises the spatial degree until it reaches the model's maximum, then the time degree.  ``sh_degree_start`` = (0, 0) is
+    the reference's training from scratch (GaussianModel starts at degree 0 / 0); None keeps the model's current active
+    degrees (resuming / fine-tuning a model whose coefficients are already populated).  ``white_background`` adds the
+    reference's extra opacity reset at ``densify_from_iter`` (train.py:243)."""
     shard = iter(FrameShard(len(cameras), batch_size, world_size, rank, seed))
     steppipe = StepPipeline(model, optimizer, world_size=world_size, lambda_dssim=lambda_dssim)
     stats = DensificationStats(model.P, model.flat.device, world_size)
-    max_deg = model.active_sh_degree if max_sh_degree is None else max_sh_degree
+    if sh_degree_start is not None:
+        model.active_sh_degree = min(int(sh_degree_start[0]), model.max_sh_degree)
+        model.active_sh_degree_t = min(int(sh_degree_start[1]), model.max_sh_degree_t)
     hist: Dict[str, List[float]] = {"iteration": [], "loss": [], "psnr": []}
     for iteration in range(1, iterations + 1):
         optimizer.set_lr("_xyz", expon_lr(iteration, position_lr_init, position_lr_final, 0, position_lr_delay_mult,
                                           position_lr_max_steps))                       # gaussian_model.py:359-365
-        if iteration % sh_increase_interval == 0 and model.active_sh_degree < max_deg:  # train.py:95-96
-            model.active_sh_degree += 1
+        if iteration % sh_increase_interval == 0:                                       # train.py:93-94
+            model.oneupSHdegree()
         idx = next(shard)
         results, losses = steppipe.step([cameras[i] for i in idx], [gts[i] for i in idx], pipe, bg)
         if iteration < densify_until_iter:                                              # train.py:229-244
@@ -183,7 +200,7 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
                         if rank == 0 and log_every:
                             log("[it %5d] densify: %d -> %d Gaussians (%d cloned, %d split)" % (iteration, rep["P_old"], rep["P_new"],
                                                                                               rep["cloned"], rep["split_parents"]))
-                    if iteration % opacity_reset_interval == 0:                                          # train.py:242-243
+                    if iteration % opacity_reset_interval == 0 or (white_background and iteration == densify_from_iter):   # train.py:243
                         from .densify import reset_opacity
                         reset_opacity(model, optimizer)
         if log_every and (iteration % log_every == 0 or iteration == 1 or iteration == iterations):
@@ -192,5 +209,6 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
                 p = float(psnr(results[-1]["render"], gts[idx[-1]]).mean())
             hist["iteration"].append(iteration); hist["loss"].append(loss); hist["psnr"].append(p)
             if rank == 0:
-                log("[it %5d] loss %.5f  psnr %.2f dB  (%d Gaussians, SH degree %d)" % (iteration, loss, p, model.P, model.active_sh_degree))
+                log("[it %5d] loss %.5f  psnr %.2f dB  (%d Gaussians, SH degree %d / time %d)" % (iteration, loss, p, model.P,
+                                                                                                 model.active_sh_degree, model.active_sh_degree_t))
     return hist

@@ -56,14 +56,25 @@ class GaussianParams:
         with torch.no_grad():
             for name in self.NAMES:
                 self.params[name].copy_(init[name].to(device).reshape(shapes[name]))
-        self.active_sh_degree = int(scene["sh_degree"])
-        self.active_sh_degree_t = int(scene["sh_degree_t"])
+        # the coefficient storage (M) is laid out for these maxima; a model built from a scene starts with all of them active
+        # (a trained model); training from scratch starts at (0, 0) and ramps with oneupSHdegree() (harness.train)
+        self.max_sh_degree = int(scene["sh_degree"])
+        self.max_sh_degree_t = int(scene["sh_degree_t"])
+        self.active_sh_degree = self.max_sh_degree
+        self.active_sh_degree_t = self.max_sh_degree_t
         self.time_duration = [0.0, float(scene["time_duration"])]
         self.rot_4d, self.gaussian_dim = bool(scene["rot_4d"]), int(scene["gaussian_dim"])
         self.force_sh_3d = bool(scene["force_sh_3d"])
         self.prefilter_var = -1.0
         self.env_map = None
         self.get_max_sh_channels = M
+
+    def oneupSHdegree(self):
+        """scene/gaussian_model.py:253-257: the spatial degree climbs to its maximum first, then the time degree."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+        elif self.max_sh_degree_t and self.active_sh_degree_t < self.max_sh_degree_t:
+            self.active_sh_degree_t += 1
 
     def row_floats(self) -> List[int]:
         """floats per Gaussian of every segment of the flat bucket, in NAMES order"""
@@ -188,6 +199,9 @@ class FlatAdam:
         n = end - begin
         if n <= 0:
             return
+        if begin % 4 != 0:
+            raise ValueError("FlatAdam.step_range: begin must be a multiple of 4 elements (the kernel updates float4s; "
+                             "allreduce_and_step cuts its chunks accordingly), got %d" % begin)
         if m.flat.is_cuda:
             from . import _capi
             # segment table relative to `begin` (a segment that starts before the chunk keeps its phase: negative begin)

@@ -210,6 +210,13 @@ int fdgs_debug_activations(int32_t P, const float* opacity_raw, const float* sca
                            const float* rotations_raw, const float* rotations_r_raw, float* opacity, float* scales,
                            float* scales_t, float* rotations, float* rotations_r, void* stream);
 
+/* Introspection for the block-cull test: the blend kernels skip a list entry for a whole 8x8 pixel block when a closed-form
+ * bound says that no pixel of the block can reach alpha >= 1/255 (csrc/blend_common.h, block_reaches).  tuples [n][10] =
+ * mean x, y, conic xx, xy, yy, opacity, rx0, rx1, ry0, ry1 (first / last pixel centre of the block in x and y); out [n][2] =
+ * { the bound's verdict, brute force: does any pixel centre of the block pass the blend kernels' own per-pixel test }.
+ * The verdict must never be 0 where the brute force says 1. */
+int fdgs_debug_block_reaches(int32_t n, const float* tuples, uint8_t* out, void* stream);
+
 /* Test hook: lists longer than `lds_cap` entries take the global-scratch sort, tiles whose most crowded depth bucket
  * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (4096, 48).  Process-wide. */
 void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);

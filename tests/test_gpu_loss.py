@@ -1,9 +1,39 @@
-"""GPU: the fused L1 + SSIM kernel (csrc/ssim.hip) against the PyTorch statement of the reference loss
-(utils/loss_utils.py:17-64 via fdgs.train_host.photometric_loss, evaluated on the CPU in float64 and on the GPU)."""
+"""GPU: the fused L1 + SSIM kernel (csrc/ssim.hip) against (a) fixtures produced by the reference's own
+utils/loss_utils.py in float64 (tests/golden/make_golden_ssim.py) and (b) the PyTorch statement of the same loss in
+fdgs.train_host (the --torch-loss A/B path of bench.py; itself pinned to the fixtures in tests/test_loss_host.py)."""
+import glob
+import os
+
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_fused_l1_ssim_matches_reference_fixtures(path, gpu_device):
+    """Loss value and image gradient of the HIP kernels against the reference's l1_loss / ssim (float64 fixtures)."""
+    from fdgs.loss import fused_l1_ssim, l1_ssim_value_and_grad
+    f = np.load(path)
+    lam = float(f["lam"])
+    img = torch.from_numpy(f["img"]).to(gpu_device).requires_grad_(True)
+    gt = torch.from_numpy(f["gt"]).to(gpu_device)
+    out = fused_l1_ssim(img, gt, lam)
+    out.backward()
+    assert abs(out.item() - float(f["loss"])) <= 2e-6, (out.item(), float(f["loss"]))
+    want = f["dloss_dimg"]
+    scale = float(np.abs(want).max())
+    err = float(np.abs(img.grad.cpu().numpy().astype(np.float64) - want).max())
+    print(os.path.basename(path), "loss err %.2e, gradient max abs err %.2e (max|ref| %.2e)" % (abs(out.item() - float(f["loss"])), err, scale))
+    assert err <= 1e-4 * scale, (err, scale)
+    # the no-autograd entry the step pipeline uses gives the same numbers
+    up = torch.full((1,), 2.5, dtype=torch.float32, device=gpu_device)
+    val, g = l1_ssim_value_and_grad(img.detach(), gt, lam, up)
+    assert abs(val.item() - float(f["loss"])) <= 2e-6
+    assert float(np.abs(g.cpu().numpy().astype(np.float64) - 2.5 * want).max()) <= 2.5e-4 * scale
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 64), (3, 77, 131), (3, 338, 450), (1, 40, 33)])

@@ -70,3 +70,25 @@ def test_densification_stats_match_reference_statement():
     np.testing.assert_allclose(st.t_gradient_accum.numpy(), ref[1].numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(st.denom.numpy(), ref[2].numpy())
     np.testing.assert_array_equal(st.max_radii2D.numpy(), ref[3].numpy())
+
+
+def test_sh_schedule_follows_oneupSHdegree():
+    """scene/gaussian_model.py:253-257 + train.py:93-94: from (0, 0) the spatial degree climbs first, then the time degree;
+    a model built from a scene starts with every degree active and the schedule leaves it alone."""
+    import torch
+    from fdgs import synth, train_host
+    cfg = synth.SceneConfig("sh", 50, 32, 32, 3, 2, 0.05, 10.0, True, 4, False)
+    m = train_host.GaussianParams(synth.make_scene(cfg, seed=0), torch.device("cpu"))
+    assert (m.max_sh_degree, m.max_sh_degree_t, m.active_sh_degree, m.active_sh_degree_t) == (3, 2, 3, 2)
+    m.oneupSHdegree()
+    assert (m.active_sh_degree, m.active_sh_degree_t) == (3, 2)
+    m.active_sh_degree, m.active_sh_degree_t = 0, 0
+    seq = []
+    for _ in range(7):
+        m.oneupSHdegree()
+        seq.append((m.active_sh_degree, m.active_sh_degree_t))
+    assert seq == [(1, 0), (2, 0), (3, 0), (3, 1), (3, 2), (3, 2), (3, 2)]
+    opt = train_host.FlatAdam(m)
+    import pytest
+    with pytest.raises(ValueError, match="multiple of 4"):
+        opt.step_range(2, 10)
