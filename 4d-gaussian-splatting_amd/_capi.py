@@ -52,7 +52,7 @@ class FdgsBackwardOut(C.Structure):
     _fields_ = [("dL_dmeans2D", _fp), ("dL_dcolors", _fp), ("dL_dopacity", _fp), ("dL_dmeans3D", _fp),
                 ("dL_dcov3D", _fp), ("dL_dsh", _fp), ("dL_dflows", _fp), ("dL_dts", _fp), ("dL_dscales", _fp),
                 ("dL_dscales_t", _fp), ("dL_drotations", _fp), ("dL_drotations_r", _fp), ("accumulate", C.c_int32),
-                ("grad_accum", _fp), ("grad_accum_clean", C.c_int32)]
+                ("grad_accum", _fp), ("grad_accum_clean", C.c_int32), ("stage_mask", C.c_int32)]
 
 
 class FdgsDebugView(C.Structure):

@@ -267,15 +267,19 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	const char* bin = (const char*)in->binning_buffer;
 	const uint32_t* point_list = (const uint32_t*)(bin + BL.point_list);
 
-	// the packed accumulator records of the blend backward start from zero
-	if (!out->grad_accum_clean)
-		STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->grad_accum, 0, (size_t)P * GRAD_ACC_WORDS * 4, stream), "memset");
-
-	if (R > 0)
-		STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
-		                       (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
-	STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
-	STAGE(FDGS_STAGE_PREPROCESS_BWD, launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
+	const int stages = (out->stage_mask & 3) ? (out->stage_mask & 3) : 3;
+	if (stages & 1)
+	{
+		// the packed accumulator records of the blend backward start from zero
+		if (!out->grad_accum_clean)
+			STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->grad_accum, 0, (size_t)P * GRAD_ACC_WORDS * 4, stream), "memset");
+		if (R > 0)
+			STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
+			                       (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
+		STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
+	}
+	if (stages & 2)
+		STAGE(FDGS_STAGE_PREPROCESS_BWD, launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
 	return FDGS_OK;
 }
 

@@ -19,7 +19,7 @@ import torch
 
 from .fused import raw_backward, raw_forward, raw_settings
 from .loss import l1_ssim_grad, l1_ssim_loss
-from .train_host import allreduce_and_step
+from .train_host import allreduce_and_step, allreduce_sh_begin
 
 
 class StepPipeline:
@@ -56,6 +56,7 @@ class StepPipeline:
             with torch.cuda.stream(self.sB):
                 self._gacc = torch.zeros((m.P, 16), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
+        sh_handle = []
         for b in range(B):
             with torch.cuda.stream(self.sF):
                 rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
@@ -67,9 +68,15 @@ class StepPipeline:
             with torch.cuda.stream(self.sB):
                 self.sB.wait_event(ev)
                 g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
+                # last view of the step on several ranks: the SH gradients (88 % of the bucket) are final once this view's
+                # SH backward has run -- their all-reduce starts there and travels while the geometry backward runs
+                after_sh = None
+                if self.world > 1 and b == B - 1:
+                    def after_sh():
+                        sh_handle.append(allreduce_sh_begin(m, self.world))
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
-                                     self.sink, b > 0, grad_accum=self._gacc)
+                                     self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh)
                 loss = l1_ssim_loss(loss_handle)   # the small reduction goes behind the backward, off the critical path
             # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
             keep.append((geom, binb, img, out_means3D, g_color, T))
@@ -78,7 +85,7 @@ class StepPipeline:
             losses.append(loss)
         with torch.cuda.stream(self.sB):
             # the losses were scaled by 1 / (B * world): SUM = mean; Adam on chunk k overlaps the all-reduce of chunk k+1
-            allreduce_and_step(m, self.opt, self.world, chunks=4, average=False)
+            allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)
         self.sF.wait_stream(self.sB)

@@ -39,7 +39,9 @@ class GaussianParams:
     applied per coefficient by the optimizer's segment table instead.
     """
 
-    NAMES = ("_xyz", "_features", "_opacity", "_scaling", "_rotation", "_t", "_scaling_t", "_rotation_r")
+    # bucket order: the small geometry tensors first (17 floats per Gaussian), the SH coefficients last (3 M = 144): the two
+    # parts are final at different moments of a backward pass and are all-reduced separately (allreduce_and_step)
+    NAMES = ("_xyz", "_opacity", "_scaling", "_rotation", "_t", "_scaling_t", "_rotation_r", "_features")
 
     def __init__(self, scene: Dict[str, object], device):
         """``scene``: post-activation tensors from fdgs.synth.make_scene; raw parameters are their inverses."""
@@ -78,7 +80,7 @@ class GaussianParams:
 
     def row_floats(self) -> List[int]:
         """floats per Gaussian of every segment of the flat bucket, in NAMES order"""
-        return [3, self.M * 3, 1, 3, 4, 1, 1, 4]
+        return [3, 1, 3, 4, 1, 1, 4, self.M * 3]
 
     def floats_per_gaussian(self) -> int:
         return sum(self.row_floats())
@@ -87,6 +89,7 @@ class GaussianParams:
         """(Re)creates the parameter views over ``flat`` / ``flat_grad`` for P Gaussians (segments back to back)."""
         shapes = {"_xyz": (P, 3), "_features": (P, self.M, 3), "_opacity": (P, 1), "_scaling": (P, 3), "_rotation": (P, 4),
                   "_t": (P, 1), "_scaling_t": (P, 1), "_rotation_r": (P, 4)}
+        assert self.NAMES[-1] == "_features"
         assert flat.numel() == flat_grad.numel() == P * self.floats_per_gaussian()
         self.flat, self.flat_grad = flat, flat_grad
         self.params = {}
@@ -243,22 +246,57 @@ def allreduce_gradients(model: GaussianParams, world_size: int, average: bool = 
             model.flat_grad.mul_(1.0 / world_size)
 
 
-def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: int, chunks: int = 4, average: bool = False) -> None:
-    """Gradient all-reduce + Adam with the two overlapped: the bucket is cut into ``chunks`` pieces, all all-reduces
-    are issued at once (they run back to back on the collective stream) and chunk k is updated as soon as ITS
-    all-reduce has finished, while chunk k+1 is still on the wire.  Same result as allreduce_gradients + step()."""
+def _bounds(begin: int, end: int, pieces: int):
+    """[begin, end) cut into at most ``pieces`` runs whose starts are multiples of 4 elements (the Adam kernel's float4 path)."""
+    n = end - begin
+    pieces = max(1, min(int(pieces), n))
+    step = -(-n // pieces)
+    step += (-step) % 4
+    return [(b, min(b + step, end)) for b in range(begin, end, step)]
+
+
+def _sh_split(model: GaussianParams) -> int:
+    """First element of the part of the bucket that is all-reduced early: the start of the SH gradients rounded up to a
+    multiple of 4 elements (Adam's float4 path); the up to 3 SH values before it travel with the geometry part."""
+    b = model.offsets["_features"][0]
+    return b + (-b) % 4
+
+
+def allreduce_sh_begin(model: GaussianParams, world_size: int, chunks: int = 3):
+    """Starts the all-reduce of the SH-gradient part of the bucket (asynchronously, in ``chunks`` pieces) and returns the
+    handle for ``allreduce_and_step(..., sh_handle=...)``.  To be called as soon as the last view's SH backward has been
+    enqueued -- the geometry backward of that view has not run yet, and does not touch this part of the bucket.
+    The caller's CURRENT stream must be one on which the SH gradients are complete (torch.distributed orders the
+    collective behind the current stream's work)."""
+    if world_size <= 1:
+        return None
+    import torch.distributed as dist
+    bounds = _bounds(_sh_split(model), model.flat.numel(), chunks)
+    return [(dist.all_reduce(model.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi) for lo, hi in bounds]
+
+
+def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: int, chunks: int = 4, average: bool = False,
+                       sh_handle=None) -> None:
+    """Gradient all-reduce + Adam with the two overlapped: the bucket is cut into pieces, all all-reduces are issued
+    at once (they run back to back on the collective stream) and a piece is updated as soon as ITS all-reduce has
+    finished, while the next one is still on the wire.  ``sh_handle``: the SH part is already in flight
+    (allreduce_sh_begin), only the geometry part (17 floats per Gaussian) is issued here.
+    Same result as allreduce_gradients + step() (sums are element-wise: the cut does not change them)."""
     if world_size <= 1:
         optimizer.step()
         return
     import torch.distributed as dist
     n = model.flat.numel()
-    chunks = max(1, min(int(chunks), n))
-    step = -(-n // chunks)
-    step += (-step) % 4                      # 16-byte aligned pieces (the Adam kernel's float4 path)
-    bounds = [(b, min(b + step, n)) for b in range(0, n, step)]
-    works = [dist.all_reduce(model.flat_grad[b:e], op=dist.ReduceOp.SUM, async_op=True) for b, e in bounds]
+    geo_end = _sh_split(model)
+    if sh_handle is None:
+        pieces = _bounds(0, n, chunks)
+    else:
+        pieces = _bounds(0, geo_end, 1)
+    works = [(dist.all_reduce(model.flat_grad[b:e], op=dist.ReduceOp.SUM, async_op=True), b, e) for b, e in pieces]
+    if sh_handle is not None:
+        works = list(sh_handle) + works     # the SH pieces were issued first and finish first
     optimizer.step_count += 1
-    for w, (b, e) in zip(works, bounds):
+    for w, b, e in works:
         w.wait()
         if average:
             model.flat_grad[b:e].mul_(1.0 / world_size)

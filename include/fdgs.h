@@ -160,6 +160,10 @@ typedef struct fdgs_backward_out
 	int32_t grad_accum_clean; /* 0: the call clears grad_accum itself (one memset per backward).
 	                             1: the caller guarantees it is all zero on entry (a persistent buffer, zeroed once) and
 	                                the call leaves it all zero on exit: the last kernel re-zeroes what it has read */
+	int32_t stage_mask;       /* 0 (or 3): the whole backward.  1: blend backward + SH backward only -- dL_dsh is final when
+	                             they have run; 2: the geometry backward only (must follow a call with 1 on the same
+	                             stream, same arguments).  Lets a data-parallel caller start the all-reduce of the SH
+	                             gradients (88 % of the bytes at M = 48) while the geometry backward still runs. */
 } fdgs_backward_out;
 
 /* Forward pass: preprocess -> tile count -> tile scan -> [R read back] -> tile scatter -> per-tile

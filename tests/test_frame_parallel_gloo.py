@@ -60,6 +60,27 @@ def _worker(rank, world, port, q):
             train_host.allreduce_and_step(twin, twin_opt, world, chunks=5, average=True)
             opt.step()
             assert torch.equal(twin.flat, model.flat) and torch.equal(twin_opt.exp_avg_sq, opt.exp_avg_sq)
+        elif step == 2:
+            # split path of the step pipeline: the SH part of the bucket is all-reduced EARLY (while, on the GPU, the last
+            # view's geometry backward still runs -- here the geometry gradients are simply written afterwards), the
+            # geometry part later; must equal one all-reduce over the whole bucket followed by one Adam step, bit for bit
+            twin = train_host.GaussianParams(scene, torch.device("cpu"))
+            twin_opt = train_host.make_optimizer(twin)
+            assert twin.offsets["_features"][0] == 257 * 17 and twin.NAMES[-1] == "_features"
+            geo_end = train_host._sh_split(twin)     # 4369 -> 4372: cut on a float4 boundary
+            assert geo_end == 4372
+            with torch.no_grad():
+                twin.flat.copy_(model.flat)
+                twin.flat_grad[geo_end:].copy_(local[geo_end:])            # SH gradients final ...
+                twin.flat_grad[:geo_end].fill_(float("nan"))               # ... geometry gradients not written yet
+            twin_opt.exp_avg.copy_(opt.exp_avg); twin_opt.exp_avg_sq.copy_(opt.exp_avg_sq); twin_opt.step_count = opt.step_count
+            handle = train_host.allreduce_sh_begin(twin, world, chunks=3)
+            with torch.no_grad():
+                twin.flat_grad[:geo_end].copy_(local[:geo_end])            # the geometry backward finishes
+            train_host.allreduce_and_step(twin, twin_opt, world, average=True, sh_handle=handle)
+            opt.step()
+            assert torch.equal(twin.flat_grad, model.flat_grad)
+            assert torch.equal(twin.flat, model.flat) and torch.equal(twin_opt.exp_avg_sq, opt.exp_avg_sq)
         else:
             opt.step()
         flats = [torch.zeros_like(model.flat) for _ in range(world)]
