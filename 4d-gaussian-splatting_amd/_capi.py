@@ -52,7 +52,7 @@ class FdgsBackwardOut(C.Structure):
     _fields_ = [("dL_dmeans2D", _fp), ("dL_dcolors", _fp), ("dL_dopacity", _fp), ("dL_dmeans3D", _fp),
                 ("dL_dcov3D", _fp), ("dL_dsh", _fp), ("dL_dflows", _fp), ("dL_dts", _fp), ("dL_dscales", _fp),
                 ("dL_dscales_t", _fp), ("dL_drotations", _fp), ("dL_drotations_r", _fp), ("accumulate", C.c_int32),
-                ("grad_accum", _fp), ("grad_accum_clean", C.c_int32), ("stage_mask", C.c_int32)]
+                ("grad_accum", _fp), ("grad_accum_clean", C.c_int32), ("sh_stage", _fp), ("stage_mask", C.c_int32)]
 
 
 class FdgsDebugView(C.Structure):
@@ -70,7 +70,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_profile_enable", "fdgs_profile_read",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
@@ -105,6 +105,8 @@ def _load():
     lib.fdgs_debug_tile_sort_limits.restype = None
     lib.fdgs_debug_block_reaches.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fdgs_debug_block_reaches.restype = C.c_int
+    lib.fdgs_sh_flush.argtypes = [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.fdgs_sh_flush.restype = C.c_int
     lib.fdgs_profile_enable.argtypes = [C.c_int]
     lib.fdgs_profile_enable.restype = C.c_int
     lib.fdgs_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -192,6 +194,19 @@ def debug_activations(opacity_raw=None, scales_raw=None, scales_t_raw=None, rota
         rc = lib.fdgs_debug_activations(P, *[_ptr(t) for t in ins], *[_ptr(t) for t in outs], current_stream_handle(ref.device))
     _check(rc, "fdgs_debug_activations")
     return tuple(outs)
+
+
+def sh_flush(stages, dL_dsh, sh_degree, sh_degree_t, gaussian_dim, force_sh_3d, time_duration, accumulate=False):
+    """dL_dsh from the staged views of the deferred SH backward (fdgs_sh_flush); ``stages``: [num_views, P, 8] float32
+    tensor whose slices stages[v] were the ``sh_stage`` of the views' backward calls."""
+    P, M = int(dL_dsh.shape[0]), int(dL_dsh.shape[1])
+    if stages.dim() != 3 or stages.shape[1] != P or stages.shape[2] != 8 or not stages.is_contiguous() or stages.dtype != torch.float32:
+        raise RuntimeError("fdgs: stages must be a contiguous float32 tensor [num_views, %d, 8]" % P)
+    with torch.cuda.device(dL_dsh.device):
+        rc = lib.fdgs_sh_flush(P, int(sh_degree), int(sh_degree_t), M, int(gaussian_dim), int(bool(force_sh_3d)), float(time_duration),
+                               int(stages.shape[0]), stages.data_ptr(), dL_dsh.data_ptr(), int(bool(accumulate)),
+                               current_stream_handle(dL_dsh.device))
+    _check(rc, "fdgs_sh_flush")
 
 
 def current_stream_handle(device):

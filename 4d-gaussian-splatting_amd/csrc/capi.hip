@@ -250,7 +250,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	    !in->radii || !in->out_means3D || !in->geom_buffer || !in->binning_buffer || !in->image_buffer)
 		return fail(FDGS_ERR_INVALID_ARG, "backward inputs must not be NULL");
 	if (!out->dL_dmeans2D || !out->dL_dcolors || !out->dL_dopacity || !out->dL_dmeans3D || !out->dL_dcov3D ||
-	    !out->dL_dflows || !out->grad_accum || (s.shs && !out->dL_dsh))
+	    !out->dL_dflows || !out->grad_accum || (s.shs && !out->dL_dsh && !out->sh_stage))
 		return fail(FDGS_ERR_INVALID_ARG, "backward outputs must not be NULL");
 	if (s.cov3D_precomp == nullptr)
 	{
@@ -280,6 +280,17 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	}
 	if (stages & 2)
 		STAGE(FDGS_STAGE_PREPROCESS_BWD, launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
+	return FDGS_OK;
+}
+
+extern "C" int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d, float time_duration,
+                             int32_t num_views, const float* stages, float* dL_dsh, int32_t accumulate, void* stream_v)
+{
+	g_err[0] = 0;
+	if (P < 0 || M < 0 || num_views < 1 || (P > 0 && M > 0 && (!dL_dsh || !stages)))
+		return fail(FDGS_ERR_INVALID_ARG, "fdgs_sh_flush: bad arguments");
+	HIP_TRY(launch_sh_flush(P, D, D_t, M, gaussian_dim, force_sh_3d, time_duration, num_views, stages, dL_dsh, accumulate,
+	                        (hipStream_t)stream_v), "sh_flush");
 	return FDGS_OK;
 }
 

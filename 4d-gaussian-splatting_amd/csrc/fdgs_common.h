@@ -126,6 +126,10 @@ namespace fdgs
 	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                         const char* geom, hipStream_t stream);
 
+	// once per optimizer step: dL_dsh from the staged per-view records of the deferred SH backward (sh_bwd.hip)
+	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, float time_duration, int nviews,
+	                           const float* stages, float* dL_dsh, int accumulate, hipStream_t stream);
+
 	hipError_t launch_preprocess_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                                 const char* geom, hipStream_t stream);
 

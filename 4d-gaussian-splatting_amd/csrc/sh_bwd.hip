@@ -39,6 +39,7 @@ namespace fdgs
 		int gaussian_dim, force_sh_3d, vec_ok, accum;
 		const int32_t* radii; const float* means; const uint8_t* clamped;
 		float* gacc; float* dL_dsh;
+		float4* stage;   // deferred mode: [P][2] = (dRGB.xyz, dir_t) (dir.xyz, 0) per Gaussian instead of dL_dsh (see sh_flush_kernel)
 	};
 
 	__device__ __forceinline__ float3 s_ld3(const float* p, int k) { return make_float3(p[3 * k], p[3 * k + 1], p[3 * k + 2]); }
@@ -165,6 +166,7 @@ namespace fdgs
 
 	// One wave per workgroup: the tile is wave-private, so no workgroup barrier is needed anywhere (LDS
 	// operations of one wave execute in order) and waves of different phases (load / compute / store) overlap freely.
+	template <bool STAGE>
 	__global__ void __launch_bounds__(WAVE) sh_bwd_kernel(const ShBwdArgs a)
 	{
 		__shared__ float tile[SHB_GPW * SHB_STRIDE];
@@ -231,8 +233,11 @@ namespace fdgs
 					const float3 s = s_ld3(row, k);
 					float basis = l[k];
 					if (blk == 0 && k == 1 && !sh3d) basis = l[0]; // Q1
-					const float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
-					row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
+					if (!STAGE)
+					{
+						const float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
+						row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
+					}
 					st = s_add(st, s_scl(l[k], s));
 					sx = s_add(sx, s_scl(dX[k], s));
 					sy = s_add(sy, s_scl(dY[k], s));
@@ -246,12 +251,24 @@ namespace fdgs
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
-			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
-			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
-			__builtin_amdgcn_wave_barrier();
+			if (!STAGE)
+			{
+				if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
+				else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+		if (STAGE)
+		{
+			// what the flush needs to rebuild this view's contribution basis(dir, dir_t) x dRGB to dL_dsh
+			if (valid)
+			{
+				a.stage[2 * (size_t)idx] = live ? make_float4(dRGB.x, dRGB.y, dRGB.z, dir_t) : make_float4(0.f, 0.f, 0.f, 0.f);
+				a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, 0.f);
+			}
 		}
 		// coefficients above the active degree get a zero gradient (nothing to add when accumulating)
-		if (!a.accum)
+		else if (!a.accum)
 		{
 			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
 			const int rest = (int)row_floats - written;
@@ -291,7 +308,119 @@ namespace fdgs
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
-		hipLaunchKernelGGL(sh_bwd_kernel, dim3(div_up(s.P, SHB_GPW)), dim3(WAVE), 0, stream, a);
+		a.stage = reinterpret_cast<float4*>(out.sh_stage);
+		if (out.sh_stage) hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(div_up(s.P, SHB_GPW)), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(div_up(s.P, SHB_GPW)), dim3(WAVE), 0, stream, a);
+		return hipGetLastError();
+	}
+
+	// ------------------------------------------------------------------------------------------------
+	// Deferred SH gradient (gradient accumulation over the views of one optimizer step).
+	// dL_dsh of a view is basis(view direction, time) (x) dL_dRGB: M x 3 floats written (or read-modified-written, from the
+	// second view on) per Gaussian and view, although the view only contributes 7 numbers.  In deferred mode
+	// (fdgs_backward_out.sh_stage) sh_bwd_kernel stores those 7 numbers per view and this kernel, once per step, rebuilds
+	// the views' contributions in registers, sums them in view order -- the same additions in the same order as the
+	// accumulating path, so the result is bit-identical -- and writes dL_dsh ONCE: at C3 / 4 views 1.7 KB of traffic per
+	// live Gaussian and view become 0.6 KB + 0.6 KB / 4.
+	// ------------------------------------------------------------------------------------------------
+	struct ShFlushArgs
+	{
+		int P, D, D_t, M, nviews, sh3d, vec_ok, accum;
+		float time_duration;
+		const float4* stages;   // [nviews][P][2]
+		float* dL_dsh;
+	};
+
+	// basis values only (sh_tables without the derivative tables)
+	__device__ __forceinline__ void sh_values(int deg, float x, float y, float z, bool promote, float* l)
+	{
+		float dX[16], dY[16], dZ[16];
+		sh_tables(deg, x, y, z, promote, l, dX, dY, dZ);
+	}
+
+	__global__ void __launch_bounds__(WAVE) sh_flush_kernel(const ShFlushArgs a)
+	{
+		__shared__ float tile[SHB_GPW * SHB_STRIDE];
+		const int lane = threadIdx.x;
+		float* row = tile + (lane < SHB_GPW ? lane : 0) * SHB_STRIDE;
+		const int g0 = blockIdx.x * SHB_GPW;
+		const int tid_g = g0 + lane;
+		const bool valid = lane < SHB_GPW && tid_g < a.P;
+		const int idx = valid ? tid_g : a.P - 1;
+		const size_t row_floats = (size_t)3 * a.M;
+		const bool sh3d = a.sh3d != 0;
+		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
+		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+		bool any = false;
+		for (int v = 0; v < a.nviews; v++)
+		{
+			const float4 s0 = a.stages[2 * ((size_t)v * a.P + idx)];
+			any = any || (valid && (s0.x != 0.f || s0.y != 0.f || s0.z != 0.f));
+		}
+		const unsigned long long vmask = __ballot(any);
+		for (int blk = 0; blk < nblocks; blk++)
+		{
+			const int nk = (blk == 0) ? ncoef0 : 16;
+			const int first_float = 48 * blk;
+			const bool vec = a.vec_ok && nk == 16;
+			if (any)
+			{
+				// the wave-private LDS row is the accumulator: the first live view writes, the following ones add (same
+				// additions, same order as backward calls accumulating into dL_dsh view after view)
+				bool first = true;
+				for (int v = 0; v < a.nviews; v++)
+				{
+					const float4 s0 = a.stages[2 * ((size_t)v * a.P + idx)], s1 = a.stages[2 * ((size_t)v * a.P + idx) + 1];
+					const float3 dRGB = make_float3(s0.x, s0.y, s0.z);
+					if (dRGB.x == 0.f && dRGB.y == 0.f && dRGB.z == 0.f) continue;   // this view added nothing
+					float l[16];
+					sh_values(a.D, s1.x, s1.y, s1.z, !sh3d, l);
+					const float dir_t = s0.w;
+					float tk = 1.f;
+					if (blk == 1) tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
+					else if (blk == 2) tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+#pragma unroll
+					for (int k = 0; k < 16; k++)
+					{
+						if (k < nk)
+						{
+							float basis = l[k];
+							if (blk == 0 && k == 1 && !sh3d) basis = l[0]; // Q1
+							float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
+							if (!first) d = s_add(s_ld3(row, k), d);
+							row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
+						}
+					}
+					first = false;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
+			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
+			__builtin_amdgcn_wave_barrier();
+		}
+		if (!a.accum)
+		{
+			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
+			const int rest = (int)row_floats - written;
+			if (rest > 0) tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written, rest > 48 ? 48 : rest, 0ull, lane, false);
+			for (int done = 48; done < rest; done += 48)
+				tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written + done, min(48, rest - done), 0ull, lane, false);
+		}
+	}
+
+	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, float time_duration, int nviews,
+	                           const float* stages, float* dL_dsh, int accumulate, hipStream_t stream)
+	{
+		if (P <= 0 || M <= 0 || nviews <= 0) return hipSuccess;
+		ShFlushArgs a;
+		a.P = P; a.D = D; a.D_t = D_t; a.M = M; a.nviews = nviews;
+		a.sh3d = (gaussian_dim == 3 || force_sh_3d) ? 1 : 0;
+		a.vec_ok = ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0 && (3 * M) % 4 == 0) ? 1 : 0;
+		a.accum = accumulate; a.time_duration = time_duration;
+		a.stages = reinterpret_cast<const float4*>(stages);
+		a.dL_dsh = dL_dsh;
+		hipLaunchKernelGGL(sh_flush_kernel, dim3(div_up(P, SHB_GPW)), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
 	}
 }

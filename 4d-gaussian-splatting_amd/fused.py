@@ -33,7 +33,8 @@ def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, ro
 
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
-                 prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=None, after_sh=None):
+                 prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=None, after_sh=None,
+                 sh_stage=None):
     """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple."""
     e = torch.Tensor([])
     args = (rs.bg, means3D, out_means3D, radii, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
@@ -41,7 +42,7 @@ def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_r
             rs.tanfovy, g_color, g_depth, g_alpha, g_flow, sh, rs.sh_degree, rs.sh_degree_t, rs.campos,
             rs.timestamp, rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, geom, R, binb, img, rs.debug)
     return _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum,
-                                           after_sh=after_sh)
+                                           after_sh=after_sh, sh_stage=sh_stage)
 
 
 def raw_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0):

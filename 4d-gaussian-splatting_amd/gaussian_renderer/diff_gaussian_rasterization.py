@@ -134,7 +134,7 @@ class _NativeRasterizer:
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
                                      imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False, grad_accum=None,
-                                     after_sh=None):
+                                     after_sh=None, sh_stage=None):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
@@ -143,7 +143,9 @@ class _NativeRasterizer:
         ``grad_accum``: a persistent all-zero [P,16] float32 scratch tensor owned by the caller -- the call then skips
         its memset and leaves the tensor all zero again (fdgs_backward_out.grad_accum_clean);
         ``after_sh``: a callable invoked between the blend + SH backward and the geometry backward (two native calls,
-        fdgs_backward_out.stage_mask): dL_dsh is final at that point, so a data-parallel caller can start its all-reduce."""
+        fdgs_backward_out.stage_mask): dL_dsh is final at that point, so a data-parallel caller can start its all-reduce;
+        ``sh_stage``: a [P,8] float32 scratch tensor -> deferred SH gradient (fdgs_backward_out.sh_stage): dL_dsh is not
+        touched by this call, ``_capi.sh_flush`` builds it from the stages of all views of the step."""
         dev = means3D.device
         # The reference always receives four dense tensors (autograd materialises zeros).  Here an image gradient may
         # be None = "no upstream gradient": the kernels then skip that term (colour-only backward when only
@@ -192,7 +194,9 @@ class _NativeRasterizer:
             if grad_accum.numel() != P * 16 or grad_accum.dtype != torch.float32 or not grad_accum.is_contiguous():
                 raise RuntimeError("fdgs: grad_accum must be a contiguous float32 tensor with %d elements" % (P * 16))
             g["grad_accum"], clean = grad_accum, 1
-        bout = _capi.FdgsBackwardOut(*ptrs, int(bool(accumulate)), _capi._ptr(g["grad_accum"]), clean, 0)
+        if sh_stage is not None and (sh_stage.numel() != P * 8 or sh_stage.dtype != torch.float32 or not sh_stage.is_contiguous()):
+            raise RuntimeError("fdgs: sh_stage must be a contiguous float32 tensor with %d elements" % (P * 8))
+        bout = _capi.FdgsBackwardOut(*ptrs, int(bool(accumulate)), _capi._ptr(g["grad_accum"]), clean, _capi._ptr(sh_stage), 0)
         with torch.cuda.device(dev):
             if after_sh is None:
                 rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),

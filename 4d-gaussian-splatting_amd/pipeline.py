@@ -17,6 +17,7 @@ from typing import List, Sequence
 
 import torch
 
+from . import _capi
 from .fused import raw_backward, raw_forward, raw_settings
 from .loss import l1_ssim_grad, l1_ssim_loss
 from .train_host import allreduce_and_step, allreduce_sh_begin
@@ -35,6 +36,7 @@ class StepPipeline:
         self.sink = model.grad_sink()
         self._up = {}
         self._gacc = None   # persistent, always-zero blend-backward accumulator (no memset per view)
+        self._sh_stage = None   # [B, P, 8]: deferred SH gradient (fdgs_backward_out.sh_stage), flushed once per step
 
     def _upstream(self, B):
         if B not in self._up:
@@ -55,6 +57,12 @@ class StepPipeline:
         if self._gacc is None or self._gacc.shape[0] != m.P:
             with torch.cuda.stream(self.sB):
                 self._gacc = torch.zeros((m.P, 16), dtype=torch.float32, device=self.dev)
+        # deferred SH gradient: with B > 1 views per step every view stages the 7 numbers it contributes to dL_dsh and ONE
+        # flush per step writes the 3 M floats per Gaussian (instead of a read-modify-write of them per view)
+        defer_sh = B > 1
+        if defer_sh and (self._sh_stage is None or self._sh_stage.shape[0] != B or self._sh_stage.shape[1] != m.P):
+            with torch.cuda.stream(self.sB):
+                self._sh_stage = torch.empty((B, m.P, 8), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
         sh_handle = []
         for b in range(B):
@@ -71,12 +79,17 @@ class StepPipeline:
                 # last view of the step on several ranks: the SH gradients (88 % of the bucket) are final once this view's
                 # SH backward has run -- their all-reduce starts there and travels while the geometry backward runs
                 after_sh = None
-                if self.world > 1 and b == B - 1:
+                if b == B - 1 and (defer_sh or self.world > 1):
                     def after_sh():
-                        sh_handle.append(allreduce_sh_begin(m, self.world))
+                        if defer_sh:
+                            _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
+                                           rs.force_sh_3d, rs.time_duration)
+                        if self.world > 1:
+                            sh_handle.append(allreduce_sh_begin(m, self.world))
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
-                                     self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh)
+                                     self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh,
+                                     sh_stage=self._sh_stage[b] if defer_sh else None)
                 loss = l1_ssim_loss(loss_handle)   # the small reduction goes behind the backward, off the critical path
             # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
             keep.append((geom, binb, img, out_means3D, g_color, T))

@@ -67,6 +67,8 @@ def parse_args():
                          "4 N.  1: BASELINE configs[3] as specified (N timesteps frame-parallel across N GPUs, one view "
                          "per rank and step, one gradient all-reduce per view)")
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--host-cost-steps", type=int, default=30,
+                    help="steps of the tiny-scene leg that measures the host cost per view (0 = skip, e.g. under rocprofv3)")
     ap.add_argument("--no-loss", action="store_true", help="debug: sum() loss instead of L1 + SSIM")
     ap.add_argument("--reference-host", action="store_true",
                     help="host side exactly as the reference: render() on PyTorch activations, autograd gradient accumulation")
@@ -276,7 +278,7 @@ def main():
 
     # host cost per view: the same step on a scene so small that the GPU work is negligible (wall time ~ host time)
     host_ms_per_view = None
-    if use_pipeline and rank == 0:
+    if use_pipeline and rank == 0 and args.host_cost_steps > 0:
         tiny = synth.make_scene(synth.SceneConfig("tiny", 2000, 64, 48, cfg.sh_degree, cfg.sh_degree_t, 0.05, cfg.duration,
                                                   cfg.rot_4d, cfg.gaussian_dim, cfg.force_sh_3d), seed=0)
         tm = train_host.GaussianParams(tiny, dev)
@@ -288,10 +290,10 @@ def main():
             tp.step(tcams, tgts, pipe, tbg)
         torch.cuda.synchronize(dev)
         th = time.perf_counter()
-        for _ in range(30):
+        for _ in range(args.host_cost_steps):
             tp.step(tcams, tgts, pipe, tbg)
         torch.cuda.synchronize(dev)
-        host_ms_per_view = (time.perf_counter() - th) / (30 * B) * 1e3
+        host_ms_per_view = (time.perf_counter() - th) / (args.host_cost_steps * B) * 1e3
 
     # forward-only rate (the metric's second half), outside the train-step timing
     n_fwd = args.steps * B

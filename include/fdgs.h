@@ -160,6 +160,10 @@ typedef struct fdgs_backward_out
 	int32_t grad_accum_clean; /* 0: the call clears grad_accum itself (one memset per backward).
 	                             1: the caller guarantees it is all zero on entry (a persistent buffer, zeroed once) and
 	                                the call leaves it all zero on exit: the last kernel re-zeroes what it has read */
+	float* sh_stage;          /* NULL: dL_dsh is written / accumulated by this call.  Otherwise [P,8] floats of scratch owned by the
+	                             caller: DEFERRED SH gradient -- the call leaves dL_dsh alone and stores, per Gaussian, the 7
+	                             numbers this view contributes through (its dL_dRGB, the view direction, the time offset);
+	                             fdgs_sh_flush turns the stages of all views of an optimizer step into dL_dsh in one pass. */
 	int32_t stage_mask;       /* 0 (or 3): the whole backward.  1: blend backward + SH backward only -- dL_dsh is final when
 	                             they have run; 2: the geometry backward only (must follow a call with 1 on the same
 	                             stream, same arguments).  Lets a data-parallel caller start the all-reduce of the SH
@@ -176,6 +180,14 @@ int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
 /* Backward pass: blend backward -> fused cov2D / projection / SH / covariance backward. */
 int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,
                             const fdgs_backward_out* out, void* stream);
+
+/* Deferred SH gradient, second half (see fdgs_backward_out.sh_stage): dL_dsh [P,M,3] = sum over the num_views staged views,
+ * in view order, of basis(direction, time) (x) dL_dRGB -- the same additions in the same order as backward calls that
+ * accumulate into dL_dsh view after view, with 1/3 of their memory traffic at 4 views.  stages: [num_views,P,8] floats, the
+ * sh_stage buffers of the views back to back.  accumulate != 0 adds to dL_dsh instead of overwriting it.
+ * D, D_t, M, gaussian_dim, force_sh_3d, time_duration as in fdgs_scene. */
+int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d, float time_duration,
+                  int32_t num_views, const float* stages, float* dL_dsh, int32_t accumulate, void* stream);
 
 /* present[i] = view-space z of means3D[i] > 0.2 (checkFrustum, rasterizer_impl.cu:54-67). */
 int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,

@@ -22,8 +22,8 @@ STAGE_OF = {
     "preprocess_fwd_kernel": "preprocess_fwd", "preprocess_bwd_kernel": "preprocess_bwd",
     "blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd",
     "radix_hist_kernel": "radix_sort", "radix_scan_kernel": "radix_sort", "radix_scatter_kernel": "radix_sort",
-    "emit_instances_kernel": "emit_instances", "tile_ranges_kernel": "tile_ranges",
-    "offsets_reduce_kernel": "offset_scan", "offsets_scan_sums_kernel": "offset_scan", "offsets_final_kernel": "offset_scan",
+    "tile_bin_lds_kernel<false>": "tile_count", "tile_bin_direct_kernel<false>": "tile_count", "tile_scan_kernel": "tile_scan",
+    "tile_bin_lds_kernel<true>": "tile_scatter", "tile_bin_direct_kernel<true>": "tile_scatter", "tile_sort_kernel": "tile_sort",
     "ssim_fwd_kernel": "ssim_fwd", "ssim_bwd_kernel": "ssim_bwd", "sh_bwd_kernel": "sh_bwd", "adam_kernel": "adam",
 }
 
