@@ -33,7 +33,7 @@ class FdgsScene(C.Structure):
         ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
         ("timestamp", C.c_float), ("time_duration", C.c_float),
         ("rot_4d", C.c_int32), ("gaussian_dim", C.c_int32), ("force_sh_3d", C.c_int32),
-        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("raw_params", C.c_int32),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("raw_params", C.c_int32), ("analytic_sh_grad", C.c_int32),
     ]
 
 

@@ -16,7 +16,8 @@
 // One table-driven formulation serves both the 3D and the 4D path: basis values l[k] and their x/y/z
 // derivatives for k < 16; blocks 1 and 2 reuse them times cos(2 pi j dt / T).  Bug-compatible with the
 // reference: Q1 dL_dsh[1] = l[0] * dRGB in the 4D path, Q2 sign of d cos/dt,
-// Q3 the last time block overwrites dRGB/dt, Q4 view direction from the SHIFTED mean.
+// Q3 the last time block overwrites dRGB/dt, Q4 view direction from the SHIFTED mean.  fdgs_scene.analytic_sh_grad
+// (opt-in) switches Q1-Q3 to the analytic gradient of the forward pass.
 #pragma clang fp contract(off)
 #include "fdgs_common.h"
 #include "fdgs_math.h"
@@ -36,7 +37,7 @@ namespace fdgs
 		int P, D, D_t, M;
 		const float *shs, *ts, *campos;
 		float timestamp, time_duration;
-		int gaussian_dim, force_sh_3d, vec_ok, accum;
+		int gaussian_dim, force_sh_3d, vec_ok, accum, analytic;
 		const int32_t* radii; const float* means; const uint8_t* clamped;
 		float* gacc; float* dL_dsh;
 		float4* stage;   // deferred mode: [P][2] = (dRGB.xyz, dir_t) (dir.xyz, 0) per Gaussian instead of dL_dsh (see sh_flush_kernel)
@@ -225,6 +226,7 @@ namespace fdgs
 					tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
 					dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
 				}
+				if (a.analytic) dtk_dt = -dtk_dt;   // d cos(u) / dt = -sin(u) du/dt
 				float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
 #pragma unroll
 				for (int k = 0; k < 16; k++)   // fully unrolled: the tables stay in registers (no dynamic indexing)
@@ -232,7 +234,7 @@ namespace fdgs
 					if (k >= nk) break;
 					const float3 s = s_ld3(row, k);
 					float basis = l[k];
-					if (blk == 0 && k == 1 && !sh3d) basis = l[0]; // Q1
+					if (blk == 0 && k == 1 && !sh3d && !a.analytic) basis = l[0]; // Q1
 					if (!STAGE)
 					{
 						const float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
@@ -247,7 +249,7 @@ namespace fdgs
 				else
 				{
 					gx = s_add(gx, s_scl(tk, sx)); gy = s_add(gy, s_scl(tk, sy)); gz = s_add(gz, s_scl(tk, sz));
-					gt = s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
+					gt = a.analytic ? s_add(gt, s_scl(dtk_dt, st)) : s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
@@ -264,7 +266,7 @@ namespace fdgs
 			if (valid)
 			{
 				a.stage[2 * (size_t)idx] = live ? make_float4(dRGB.x, dRGB.y, dRGB.z, dir_t) : make_float4(0.f, 0.f, 0.f, 0.f);
-				a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, 0.f);
+				a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, a.analytic ? 1.f : 0.f);
 			}
 		}
 		// coefficients above the active degree get a zero gradient (nothing to add when accumulating)
@@ -303,7 +305,7 @@ namespace fdgs
 		a.P = s.P; a.D = s.D; a.D_t = s.D_t; a.M = s.M;
 		a.shs = s.shs; a.ts = s.ts; a.campos = s.campos;
 		a.timestamp = s.timestamp; a.time_duration = s.time_duration;
-		a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+		a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.analytic = s.analytic_sh_grad;
 		a.vec_ok = ((reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (reinterpret_cast<uintptr_t>(out.dL_dsh) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
 		a.radii = in.radii; a.means = in.out_means3D;
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
@@ -385,7 +387,7 @@ namespace fdgs
 						if (k < nk)
 						{
 							float basis = l[k];
-							if (blk == 0 && k == 1 && !sh3d) basis = l[0]; // Q1
+							if (blk == 0 && k == 1 && !sh3d && s1.w == 0.f) basis = l[0]; // Q1 (s1.w: the view ran with analytic_sh_grad)
 							float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
 							if (!first) d = s_add(s_ld3(row, k), d);
 							row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;

@@ -20,6 +20,17 @@ import torch.nn as nn
 from .. import _capi
 
 
+_ANALYTIC_SH_GRAD = False
+
+
+def set_analytic_sh_gradients(on: bool) -> None:
+    """Opt-in (process-wide): the 4D-SH backward returns the analytic gradient of the forward pass instead of reproducing
+    the reference's deviations Q1-Q3 (fdgs_scene.analytic_sh_grad; backward.cu:190, 303 / 384, 403).  Default off:
+    gradients are bug-compatible with the reference."""
+    global _ANALYTIC_SH_GRAD
+    _ANALYTIC_SH_GRAD = bool(on)
+
+
 def _is_given(t) -> bool:
     return t is not None and t.numel() > 0
 
@@ -90,6 +101,7 @@ class _NativeRasterizer:
         s.rot_4d, s.gaussian_dim, s.force_sh_3d = int(bool(rot_4d)), int(gaussian_dim), int(bool(force_sh_3d))
         s.prefiltered, s.debug = int(bool(prefiltered)), int(bool(debug))
         s.raw_params = int(bool(raw_params))
+        s.analytic_sh_grad = int(_ANALYTIC_SH_GRAD)
         return s, keep
 
     def rasterize_gaussians(self, bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,

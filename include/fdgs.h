@@ -100,6 +100,11 @@ typedef struct fdgs_scene
 	                         the kernels apply the reference's activations themselves (scene/gaussian_model.py:179-219:
 	                         exp, exp, sigmoid, x / max(|x|, 1e-12) twice); backward then returns gradients w.r.t. the
 	                         raw parameters. */
+	int32_t analytic_sh_grad; /* 0 (default): the 4D-SH backward reproduces the reference's three deviations from the analytic
+	                         gradient (backward.cu:190, 303 / 384, 403): Q1 dL_dsh[1] uses the l = 0
+	                         basis value, Q2 the derivative of cos(2 pi k dt / T) has the wrong sign, Q3 the k = 2 time term
+	                         overwrites the k = 1 term in dRGB/dt.  1 (opt-in): the analytic gradient of the forward pass.
+	                         Forward results do not depend on it.  (3D SH is analytic in the reference already.) */
 } fdgs_scene;
 
 /* Forward outputs; every array is fully written by the call (no pre-zeroing needed). */

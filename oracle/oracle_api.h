@@ -105,6 +105,10 @@ typedef struct oracle_io
 	float* dL_dscale_t;  /* [P]                                                */
 	float* dL_drot;      /* [P,4]                                              */
 	float* dL_drot_r;    /* [P,4]                                              */
+
+	/* ---- mode (port oracle only; the verbatim reference build ignores it) ---- */
+	int analytic_sh;     /* != 0: analytic 4D-SH backward instead of the
+	                        reference's Q1-Q3 (backward.cu:190, 303/384, 403)  */
 } oracle_io;
 
 /* Runs preprocess -> scan -> duplicateWithKeys -> stable sort -> tile ranges

@@ -45,6 +45,7 @@ class OracleIO(C.Structure):
         ("dL_dmean2D", _F), ("dL_dconic", _F), ("dL_dopacity", _F), ("dL_dcolor", _F), ("dL_dmean3D", _F),
         ("dL_dcov3D", _F), ("dL_dsh", _F), ("dL_dflows", _F), ("dL_dts", _F), ("dL_dscale", _F),
         ("dL_dscale_t", _F), ("dL_drot", _F), ("dL_drot_r", _F),
+        ("analytic_sh", C.c_int),
     ]
 
 
@@ -162,6 +163,7 @@ class Oracle:
         io.tan_fovx, io.tan_fovy = float(s["tanfovx"]), float(s["tanfovy"])
         io.rot_4d, io.gaussian_dim = int(bool(s["rot_4d"])), int(s["gaussian_dim"])
         io.force_sh_3d, io.prefiltered = int(bool(s["force_sh_3d"])), 0
+        io.analytic_sh = int(bool(s.get("analytic_sh_grad", False)))   # port oracle only
         N = W * H
         out = self.out = {
             "out_color": np.zeros((3, H, W), np.float32), "out_flow": np.zeros((2, H, W), np.float32),
