@@ -342,7 +342,7 @@ def main():
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
                         "peak is reported as the contract asks; valu_issue_frac = VALU issue cycles per SIMD (SQ counters, "
                         "profiles/) / kernel cycles at the 2.4 GHz maximum clock is the bound this kernel actually runs against"}
-    valu = pmc_valu(dom)
+    valu = pmc_valu(dom) if cfg.name == "C3" else None   # the committed SQ-counter pass is a C3 pass
     if valu:
         valu["kernel_cycles_at_2.4GHz"] = int(dom_ms * 1e-3 * 2.4e9)
         roofline["valu"] = valu
