@@ -196,18 +196,39 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, stream), "preprocess_fwd");
 		const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
 		STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
-		STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, stream), "tile scan");
-
-		// num_rendered (and the longest tile list) read-back: the one host sync of the forward pass
-		static thread_local uint32_t* pinned = nullptr;
-		if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault), "hipHostMalloc");
+		// num_rendered (and the longest tile list) come back through a pinned, device-mapped mailbox that the scan kernel
+		// writes itself: {R, longest, ticket}.  The host spins on the ticket -- the forward's one wait for the device, as
+		// rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the ticket does not show up
+		// (a failed launch), the stream is synchronised and the error reported.
+		struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t ticket = 0; };
+		static thread_local Mailbox box;
+		if (!box.host)
 		{
-			StageTimer timer__(FDGS_STAGE_READBACK, stream);
-			HIP_TRY(hipMemcpyAsync(pinned, ctl, 8, hipMemcpyDeviceToHost, stream), "num_rendered copy");
+			void* h = nullptr;
+			HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped), "hipHostMalloc");
+			memset(h, 0, 64);
+			void* d = nullptr;
+			HIP_TRY(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
+			box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
 		}
-		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
-		R = (int)pinned[0];
-		longest = (int)pinned[1];
+		const uint32_t ticket = ++box.ticket ? box.ticket : ++box.ticket;   // never 0
+		STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev, ticket, stream), "tile scan");
+		{
+			bool arrived = false;
+			for (long spin = 0; spin < 400000000L && !arrived; spin++)   // bounded: seconds
+			{
+				arrived = __atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) == ticket;
+				// now and then: has the stream drained (or failed) without the ticket showing up?  then stop spinning
+				if (!arrived && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(stream) != hipErrorNotReady) break;
+			}
+			if (!arrived)
+			{
+				HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
+				if (__atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) != ticket) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
+			}
+		}
+		R = (int)box.host[0];
+		longest = (int)box.host[1];
 		if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
 	}
 	*num_rendered = R;

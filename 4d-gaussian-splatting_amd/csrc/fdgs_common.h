@@ -107,7 +107,8 @@ namespace fdgs
 	// preprocess_fwd, the forward's first kernel); after the scan they hold every tile list's start, after the
 	// scatter its end.  ctl[0] = R, ctl[1] = longest tile list.
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream);
-	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, hipStream_t stream);
+	// host_box (optional): device pointer of a pinned host mailbox {R, longest, ticket} the kernel writes directly
+	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, hipStream_t stream);
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs, hipStream_t stream);
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
 	                            void* big_scratch, hipStream_t stream);

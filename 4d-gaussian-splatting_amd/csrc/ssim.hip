@@ -247,22 +247,35 @@ extern "C" int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t 
 namespace fdgs
 {
 	// loss = (1 - lambda) * sum(l1) / n + lambda * (1 - sum(ssim) / n), fixed summation order (deterministic)
-	__global__ void __launch_bounds__(256) l1_ssim_finish_kernel(const float* __restrict__ partial_l1, const float* __restrict__ partial_ssim,
-	                                                             int nparts, float inv_n, float lambda_dssim, float* __restrict__ out)
+	__global__ void __launch_bounds__(1024) l1_ssim_finish_kernel(const float* __restrict__ partial_l1, const float* __restrict__ partial_ssim,
+	                                                              int nparts, float inv_n, float lambda_dssim, float* __restrict__ out)
 	{
-		__shared__ float r0[256], r1[256];
+		// 1024 threads, up to 8 partials per thread and sum in flight at once (the kernel is pure latency), then a fixed
+		// shuffle tree per wave and a fixed order over the 16 waves: deterministic
+		__shared__ float r0[16], r1[16];
 		float a = 0.f, b = 0.f;
-		for (int i = threadIdx.x; i < nparts; i += 256) { a += partial_l1[i]; b += partial_ssim[i]; }
-		r0[threadIdx.x] = a; r1[threadIdx.x] = b;
-		__syncthreads();
-		for (int o = 128; o > 0; o >>= 1)
+		for (int base = 0; base < nparts; base += 8 * 1024)
 		{
-			if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
-			__syncthreads();
+			float va[8], vb[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++)
+			{
+				const int i = base + k * 1024 + (int)threadIdx.x;
+				va[k] = i < nparts ? partial_l1[i] : 0.f;
+				vb[k] = i < nparts ? partial_ssim[i] : 0.f;
+			}
+			a += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+			b += ((vb[0] + vb[1]) + (vb[2] + vb[3])) + ((vb[4] + vb[5]) + (vb[6] + vb[7]));
 		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+		if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = a; r1[threadIdx.x >> 6] = b; }
+		__syncthreads();
 		if (threadIdx.x == 0)
 		{
-			const float l1 = r0[0] * inv_n, ss = r1[0] * inv_n;
+			float s0 = 0.f, s1 = 0.f;
+			for (int w = 0; w < 16; w++) { s0 += r0[w]; s1 += r1[w]; }
+			const float l1 = s0 * inv_n, ss = s1 * inv_n;
 			out[0] = (1.0f - lambda_dssim) * l1 + lambda_dssim * (1.0f - ss);
 			out[1] = l1;
 			out[2] = ss;
@@ -276,7 +289,7 @@ extern "C" int fdgs_l1_ssim_loss(const float* partial_l1, const float* partial_s
 	using namespace fdgs;
 	if (!partial_l1 || !partial_ssim || !loss_l1_ssim || num_partials <= 0 || C <= 0 || H <= 0 || W <= 0) return FDGS_ERR_INVALID_ARG;
 	const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial_l1, partial_ssim, num_partials, inv_n, lambda_dssim, loss_l1_ssim);
+	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial_l1, partial_ssim, num_partials, inv_n, lambda_dssim, loss_l1_ssim);
 	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
 }
 

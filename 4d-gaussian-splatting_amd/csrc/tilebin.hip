@@ -173,7 +173,7 @@ namespace fdgs
 	// ------------------------------------------------------------------------------------------------
 	constexpr int SCAN_T = 1024;
 	__global__ void __launch_bounds__(SCAN_T) tile_scan_kernel(uint32_t* __restrict__ counters, int T, int per_thread /* multiple of 4 */,
-	                                                           uint32_t* __restrict__ ctl)
+	                                                           uint32_t* __restrict__ ctl, uint32_t* __restrict__ host_box, uint32_t ticket)
 	{
 		__shared__ uint32_t s_w[SCAN_T / WAVE], s_m[SCAN_T / WAVE];
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,7 +218,17 @@ namespace fdgs
 			o.w = run; run += v.w;
 			*p = o;
 		}
-		if (threadIdx.x == 0) { ctl[0] = gtot; ctl[1] = gmax; }
+		if (threadIdx.x == 0)
+		{
+			ctl[0] = gtot; ctl[1] = gmax;
+			if (host_box)
+			{
+				// straight into the caller's pinned, device-mapped mailbox: {R, longest list}, then the call's ticket with
+				// system-scope release -- the host spins on the ticket instead of paying a copy kernel and a stream sync
+				host_box[0] = gtot; host_box[1] = gmax;
+				__hip_atomic_store(&host_box[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
 	}
 
 	// ------------------------------------------------------------------------------------------------
@@ -527,10 +537,10 @@ namespace fdgs
 		return launch_tile_bin<false>(rect, nullptr, P, grid_x, T, counters, nullptr, stream);
 	}
 
-	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, hipStream_t stream)
+	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, hipStream_t stream)
 	{
 		const int per_thread = div_up(div_up(T, SCAN_T), 4) * 4;
-		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl);
+		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl, host_box, ticket);
 		return hipGetLastError();
 	}
 

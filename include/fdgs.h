@@ -32,8 +32,8 @@
  *
  * All functions are re-entrant and keep no global state besides a thread-local
  * last-error string.  All work is enqueued on `stream`; fdgs_rasterize_forward
- * synchronises that stream once (to read back num_rendered, as the reference
- * does at rasterizer_impl.cu:302).
+ * waits for the device once (for num_rendered, as the reference does at
+ * rasterizer_impl.cu:302): it spins on a pinned mailbox the tile-scan kernel writes.
  */
 #ifndef FDGS_H
 #define FDGS_H
@@ -252,7 +252,7 @@ void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);
 #define FDGS_STAGE_TILE_SCAN 2
 #define FDGS_STAGE_TILE_SCATTER 3
 #define FDGS_STAGE_TILE_SORT 4
-#define FDGS_STAGE_READBACK 5  /* the 8-byte device-to-host copy of R (device side of the forward's one sync) */
+#define FDGS_STAGE_READBACK 5  /* unused since the scan kernel writes R into a pinned host mailbox itself (kept for numbering) */
 #define FDGS_STAGE_BLEND_FWD 6
 #define FDGS_STAGE_BLEND_BWD 7
 #define FDGS_STAGE_PREPROCESS_BWD 8

@@ -96,7 +96,7 @@ int main(int argc, char** argv)
 					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<false>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, (const float*)nullptr, P, gx, T, rounds, d_cnt, (uint2*)nullptr);
 					else hipLaunchKernelGGL(tile_bin_direct_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, (const float*)nullptr, P, gx, d_cnt, (uint2*)nullptr);
 					CK(hipEventRecord(ev[2]));
-					hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, 0, d_cnt, T, per_thread, d_ctl);
+					hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, 0, d_cnt, T, per_thread, d_ctl, (uint32_t*)nullptr, 0u);
 					CK(hipEventRecord(ev[3]));
 					CK(hipMemcpy(ctl, d_ctl, 8, hipMemcpyDeviceToHost));
 					CK(hipEventRecord(ev[6]));
