@@ -72,7 +72,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
-            "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
+            "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
 
 
@@ -105,7 +105,7 @@ def _load():
     lib.fdgs_debug_tile_sort_limits.restype = None
     lib.fdgs_debug_block_reaches.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fdgs_debug_block_reaches.restype = C.c_int
-    lib.fdgs_sh_flush.argtypes = [C.c_int32] * 6 + [C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.fdgs_sh_flush.argtypes = [C.c_int32] * 8 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.fdgs_sh_flush.restype = C.c_int
     lib.fdgs_profile_enable.argtypes = [C.c_int]
     lib.fdgs_profile_enable.restype = C.c_int
@@ -128,6 +128,8 @@ def _load():
                                    C.POINTER(FdgsAdamSegment), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
                                    C.c_void_p]
     lib.fdgs_adam_step.restype = C.c_int
+    lib.fdgs_adam_step_sh.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p] + [C.c_float] * 5 + [C.c_int32, C.c_void_p]
+    lib.fdgs_adam_step_sh.restype = C.c_int
     lib.fdgs_densify_classify.argtypes = [C.c_int32] + [C.c_void_p] * 5 + [C.c_float] * 5 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.fdgs_densify_classify.restype = C.c_int
     lib.fdgs_densify_gather.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.c_int64] + [C.c_void_p] * 9
@@ -196,17 +198,38 @@ def debug_activations(opacity_raw=None, scales_raw=None, scales_t_raw=None, rota
     return tuple(outs)
 
 
-def sh_flush(stages, dL_dsh, sh_degree, sh_degree_t, gaussian_dim, force_sh_3d, time_duration, accumulate=False):
+def sh_flush(stages, dL_dsh, sh_degree, sh_degree_t, gaussian_dim, force_sh_3d, analytic_sh_grad=False, accumulate=False):
     """dL_dsh from the staged views of the deferred SH backward (fdgs_sh_flush); ``stages``: [num_views, P, 8] float32
-    tensor whose slices stages[v] were the ``sh_stage`` of the views' backward calls."""
+    tensor whose slices stages[v] were the ``sh_stage`` of the views' backward calls; ``analytic_sh_grad``: the mode those
+    calls ran in (set_analytic_sh_gradients)."""
     P, M = int(dL_dsh.shape[0]), int(dL_dsh.shape[1])
     if stages.dim() != 3 or stages.shape[1] != P or stages.shape[2] != 8 or not stages.is_contiguous() or stages.dtype != torch.float32:
         raise RuntimeError("fdgs: stages must be a contiguous float32 tensor [num_views, %d, 8]" % P)
     with torch.cuda.device(dL_dsh.device):
-        rc = lib.fdgs_sh_flush(P, int(sh_degree), int(sh_degree_t), M, int(gaussian_dim), int(bool(force_sh_3d)), float(time_duration),
-                               int(stages.shape[0]), stages.data_ptr(), dL_dsh.data_ptr(), int(bool(accumulate)),
+        rc = lib.fdgs_sh_flush(P, int(sh_degree), int(sh_degree_t), M, int(gaussian_dim), int(bool(force_sh_3d)),
+                               int(bool(analytic_sh_grad)), int(stages.shape[0]), stages.data_ptr(), dL_dsh.data_ptr(), int(bool(accumulate)),
                                current_stream_handle(dL_dsh.device))
     _check(rc, "fdgs_sh_flush")
+
+
+def adam_step_sh(params, exp_avg, exp_avg_sq, stages, sh_degree, sh_degree_t, gaussian_dim, force_sh_3d, analytic_sh_grad,
+                 lr, lr_dc, beta1, beta2, eps, step, dL_dsh=None) -> bool:
+    """Adam over the SH coefficients ``params`` [P, M, 3] with the gradient built from the staged views (fdgs_adam_step_sh).
+    Returns False -- nothing done -- if the shape / alignment is not supported (the caller then uses sh_flush + the plain step)."""
+    P, M = int(params.shape[0]), int(params.shape[1])
+    if stages.dim() != 3 or stages.shape[1] != P or stages.shape[2] != 8 or not stages.is_contiguous() or stages.dtype != torch.float32:
+        raise RuntimeError("fdgs: stages must be a contiguous float32 tensor [num_views, %d, 8]" % P)
+    ptrs = [params.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()] + ([dL_dsh.data_ptr()] if dL_dsh is not None else [])
+    if (3 * M) % 4 != 0 or any(q % 16 for q in ptrs):
+        return False
+    with torch.cuda.device(params.device):
+        rc = lib.fdgs_adam_step_sh(params.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                   dL_dsh.data_ptr() if dL_dsh is not None else None, P, int(sh_degree), int(sh_degree_t), M,
+                                   int(gaussian_dim), int(bool(force_sh_3d)), int(bool(analytic_sh_grad)), int(stages.shape[0]),
+                                   stages.data_ptr(), float(lr), float(lr_dc), float(beta1), float(beta2), float(eps), int(step),
+                                   current_stream_handle(params.device))
+    _check(rc, "fdgs_adam_step_sh")
+    return True
 
 
 def current_stream_handle(device):

@@ -55,10 +55,7 @@ namespace fdgs
 			for (int e = 0; e < 4; e++)
 			{
 				const float lr = seg_lr(segs, 4 * q + e);
-				me[e] = b1 * me[e] + (1.f - b1) * ge[e];
-				ve[e] = b2 * ve[e] + (1.f - b2) * ge[e] * ge[e];
-				const float denom = sqrtf(ve[e]) * inv_sqrt_bc2 + eps;
-				pe[e] -= (lr * inv_bc1) * (me[e] / denom);
+				adam_update(pe[e], me[e], ve[e], ge[e], lr * inv_bc1, b1, b2, eps, inv_sqrt_bc2);
 			}
 			reinterpret_cast<float4*>(m)[q] = make_float4(me[0], me[1], me[2], me[3]);
 			reinterpret_cast<float4*>(v)[q] = make_float4(ve[0], ve[1], ve[2], ve[3]);
@@ -68,11 +65,9 @@ namespace fdgs
 		for (long long i = nvec * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
 		{
 			const float lr = seg_lr(segs, i);
-			const float gi = g[i];
-			const float mi = b1 * m[i] + (1.f - b1) * gi;
-			const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-			m[i] = mi; v[i] = vi;
-			p[i] -= (lr * inv_bc1) * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+			float pi = p[i], mi = m[i], vi = v[i];
+			adam_update(pi, mi, vi, g[i], lr * inv_bc1, b1, b2, eps, inv_sqrt_bc2);
+			m[i] = mi; v[i] = vi; p[i] = pi;
 		}
 	}
 }
@@ -98,4 +93,23 @@ extern "C" int fdgs_adam_step(float* params, const float* grads, float* exp_avg,
 	hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
 	                   (long long)n, s, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
 	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
+}
+
+extern "C" int fdgs_adam_step_sh(float* params, float* exp_avg, float* exp_avg_sq, float* dL_dsh,
+                                 int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d,
+                                 int32_t analytic_sh_grad, int32_t num_views, const float* stages,
+                                 float lr, float lr_dc, float beta1, float beta2, float eps, int32_t step, void* stream)
+{
+	using namespace fdgs;
+	if (!params || !exp_avg || !exp_avg_sq || !stages || P < 0 || M < 0 || num_views < 1 || step < 1) return FDGS_ERR_INVALID_ARG;
+	if (P == 0 || M == 0) return FDGS_OK;
+	const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+	const float inv_bc1 = (float)(1.0 / bc1);
+	AdamScalars k;
+	k.lr_bc1 = lr * inv_bc1; k.lr_head_bc1 = lr_dc * inv_bc1;
+	k.b1 = beta1; k.b2 = beta2; k.eps = eps; k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+	const hipError_t e = launch_sh_adam(P, D, D_t, M, gaussian_dim, force_sh_3d, analytic_sh_grad, num_views, stages, params, exp_avg,
+	                                    exp_avg_sq, dL_dsh, k, (hipStream_t)stream);
+	if (e == hipErrorInvalidValue) return FDGS_ERR_INVALID_ARG;   // rows not a whole number of float4s, or arrays not 16-byte aligned
+	return e == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
 }

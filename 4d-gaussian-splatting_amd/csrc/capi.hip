@@ -304,13 +304,14 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	return FDGS_OK;
 }
 
-extern "C" int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d, float time_duration,
-                             int32_t num_views, const float* stages, float* dL_dsh, int32_t accumulate, void* stream_v)
+extern "C" int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d,
+                             int32_t analytic_sh_grad, int32_t num_views, const float* stages, float* dL_dsh, int32_t accumulate,
+                             void* stream_v)
 {
 	g_err[0] = 0;
 	if (P < 0 || M < 0 || num_views < 1 || (P > 0 && M > 0 && (!dL_dsh || !stages)))
 		return fail(FDGS_ERR_INVALID_ARG, "fdgs_sh_flush: bad arguments");
-	HIP_TRY(launch_sh_flush(P, D, D_t, M, gaussian_dim, force_sh_3d, time_duration, num_views, stages, dL_dsh, accumulate,
+	HIP_TRY(launch_sh_flush(P, D, D_t, M, gaussian_dim, force_sh_3d, analytic_sh_grad, num_views, stages, dL_dsh, accumulate,
 	                        (hipStream_t)stream_v), "sh_flush");
 	return FDGS_OK;
 }

@@ -128,8 +128,15 @@ namespace fdgs
 	                         const char* geom, hipStream_t stream);
 
 	// once per optimizer step: dL_dsh from the staged per-view records of the deferred SH backward (sh_bwd.hip)
-	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, float time_duration, int nviews,
+	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, int analytic, int nviews,
 	                           const float* stages, float* dL_dsh, int accumulate, hipStream_t stream);
+
+	// once per optimizer step, instead of launch_sh_flush + Adam over the SH segment: the summed SH gradient is built in LDS and
+	// consumed by the Adam update in the same kernel (sh_bwd.hip); dL_dsh (optional) also receives it
+	struct AdamScalars { float lr_head_bc1, lr_bc1, b1, b2, eps, inv_sqrt_bc2; };
+	hipError_t launch_sh_adam(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, int analytic, int nviews,
+	                          const float* stages, float* params, float* exp_avg, float* exp_avg_sq, float* dL_dsh,
+	                          const AdamScalars& k, hipStream_t stream);
 
 	hipError_t launch_preprocess_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                                 const char* geom, hipStream_t stream);
@@ -137,6 +144,17 @@ namespace fdgs
 	hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
 
 	hipError_t launch_block_reaches_debug(int n, const float* tuples, uint8_t* out, hipStream_t stream);
+
+	// One element of torch.optim.Adam (no amsgrad / weight decay; train.py:247-249), shared by adam.hip and the fused SH
+	// update of sh_bwd.hip so that both round identically: explicit FMAs, independent of the translation unit's contraction mode.
+	__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float lr_bc1, float b1, float b2, float eps,
+	                                            float inv_sqrt_bc2)
+	{
+		m = fmaf(b1, m, (1.f - b1) * g);
+		v = fmaf(b2, v, ((1.f - b2) * g) * g);
+		const float denom = fmaf(sqrtf(v), inv_sqrt_bc2, eps);
+		p = fmaf(-lr_bc1, m / denom, p);
+	}
 
 	hipError_t launch_activations(int P, const float* opacity_raw, const float* scales_raw, const float* scales_t_raw, const float* rot_raw,
 	                              const float* rot_r_raw, float* opacity, float* scales, float* scales_t, float* rot, float* rot_r, hipStream_t stream);

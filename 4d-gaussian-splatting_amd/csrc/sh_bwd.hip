@@ -40,7 +40,7 @@ namespace fdgs
 		int gaussian_dim, force_sh_3d, vec_ok, accum, analytic;
 		const int32_t* radii; const float* means; const uint8_t* clamped;
 		float* gacc; float* dL_dsh;
-		float4* stage;   // deferred mode: [P][2] = (dRGB.xyz, dir_t) (dir.xyz, 0) per Gaussian instead of dL_dsh (see sh_flush_kernel)
+		float4* stage;   // deferred mode: [P][2] = (dRGB.xyz, cos factor of time block 1) (dir.xyz, cos factor of block 2) per Gaussian instead of dL_dsh (see sh_flush_kernel)
 	};
 
 	__device__ __forceinline__ float3 s_ld3(const float* p, int k) { return make_float3(p[3 * k], p[3 * k + 1], p[3 * k + 2]); }
@@ -205,6 +205,7 @@ namespace fdgs
 		sh_tables(a.D, dir.x, dir.y, dir.z, !sh3d, l, dX, dY, dZ);
 
 		float3 gx = make_float3(0.f, 0.f, 0.f), gy = gx, gz = gx, gt = gx;
+		float tk_stage[2] = { 0.f, 0.f };   // cos factors of the two time blocks (deferred mode hands them to the flush)
 		for (int blk = 0; blk < nblocks; blk++)
 		{
 			const int nk = (blk == 0) ? ncoef0 : 16;
@@ -227,6 +228,8 @@ namespace fdgs
 					dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
 				}
 				if (a.analytic) dtk_dt = -dtk_dt;   // d cos(u) / dt = -sin(u) du/dt
+				if (blk == 1) tk_stage[0] = tk;
+				if (blk == 2) tk_stage[1] = tk;
 				float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
 #pragma unroll
 				for (int k = 0; k < 16; k++)   // fully unrolled: the tables stay in registers (no dynamic indexing)
@@ -262,11 +265,11 @@ namespace fdgs
 		}
 		if (STAGE)
 		{
-			// what the flush needs to rebuild this view's contribution basis(dir, dir_t) x dRGB to dL_dsh
+			// what the flush needs to rebuild this view's contribution basis(dir) x time factor x dRGB to dL_dsh
 			if (valid)
 			{
-				a.stage[2 * (size_t)idx] = live ? make_float4(dRGB.x, dRGB.y, dRGB.z, dir_t) : make_float4(0.f, 0.f, 0.f, 0.f);
-				a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, a.analytic ? 1.f : 0.f);
+				a.stage[2 * (size_t)idx] = live ? make_float4(dRGB.x, dRGB.y, dRGB.z, tk_stage[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+				a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, tk_stage[1]);
 			}
 		}
 		// coefficients above the active degree get a zero gradient (nothing to add when accumulating)
@@ -318,19 +321,34 @@ namespace fdgs
 
 	// ------------------------------------------------------------------------------------------------
 	// Deferred SH gradient (gradient accumulation over the views of one optimizer step).
-	// dL_dsh of a view is basis(view direction, time) (x) dL_dRGB: M x 3 floats written (or read-modified-written, from the
-	// second view on) per Gaussian and view, although the view only contributes 7 numbers.  In deferred mode
-	// (fdgs_backward_out.sh_stage) sh_bwd_kernel stores those 7 numbers per view and this kernel, once per step, rebuilds
-	// the views' contributions in registers, sums them in view order -- the same additions in the same order as the
-	// accumulating path, so the result is bit-identical -- and writes dL_dsh ONCE: at C3 / 4 views 1.7 KB of traffic per
-	// live Gaussian and view become 0.6 KB + 0.6 KB / 4.
+	// dL_dsh of a view is basis(view direction) x time factor (x) dL_dRGB: M x 3 floats written (or read-modified-written,
+	// from the second view on) per Gaussian and view, although the view only contributes 8 numbers.  In deferred mode
+	// (fdgs_backward_out.sh_stage) sh_bwd_kernel stores those 8 numbers per view and this kernel, once per step, rebuilds
+	// the views' contributions in registers and sums them in view order -- the same additions in the same order as the
+	// accumulating path.  Two consumers:
+	//   MODE 0 (fdgs_sh_flush)      dL_dsh is written once: at C3 / 4 views 1.7 KB of traffic per live Gaussian and view
+	//                               become 0.6 KB + 0.6 KB / 4;
+	//   MODE 1 (fdgs_adam_step_sh)  the only reader of the summed dL_dsh is the Adam update of the SH coefficients
+	//                               (train.py:247-249; 89 % of all parameters at M = 48), so the gradient goes from the LDS
+	//                               tile straight into it: read p, m, v, write p, m, v (24 B per coefficient) and dL_dsh
+	//                               never travels through memory (it is also written when the caller asks for it).
+	// A wave owns 32 consecutive Gaussians; lane = (Gaussian, half of the 16 coefficients of a block), the three possible
+	// coefficient blocks accumulate in registers and land in a wave-private LDS tile of whole rows, so that the output phase
+	// walks memory strictly linearly (32 x 12 M bytes per array) -- the block-by-block sweeps of sh_bwd_kernel touch every
+	// 128-byte line of the 576-byte rows up to three times.
 	// ------------------------------------------------------------------------------------------------
+	constexpr int SHF_GPW = 32;
+	constexpr int SHF_ACT = 144;                // floats of the three coefficient blocks that can be active
+	constexpr int SHF_STRIDE = SHF_ACT + 1;     // odd: lane-per-row accesses are conflict free
+	constexpr int SHF_BATCH = 6;                // float4 chunks per lane whose p / m / v loads are in flight together
+
 	struct ShFlushArgs
 	{
-		int P, D, D_t, M, nviews, sh3d, vec_ok, accum;
-		float time_duration;
+		int P, D, D_t, M, nviews, sh3d, analytic, accum, vec_ok;
 		const float4* stages;   // [nviews][P][2]
 		float* dL_dsh;
+		float *p, *m, *v;       // MODE 1
+		AdamScalars k;
 	};
 
 	// basis values only (sh_tables without the derivative tables)
@@ -340,89 +358,185 @@ namespace fdgs
 		sh_tables(deg, x, y, z, promote, l, dX, dY, dZ);
 	}
 
+	template <int MODE>
 	__global__ void __launch_bounds__(WAVE) sh_flush_kernel(const ShFlushArgs a)
 	{
-		__shared__ float tile[SHB_GPW * SHB_STRIDE];
-		const int lane = threadIdx.x;
-		float* row = tile + (lane < SHB_GPW ? lane : 0) * SHB_STRIDE;
-		const int g0 = blockIdx.x * SHB_GPW;
-		const int tid_g = g0 + lane;
-		const bool valid = lane < SHB_GPW && tid_g < a.P;
-		const int idx = valid ? tid_g : a.P - 1;
-		const size_t row_floats = (size_t)3 * a.M;
+		__shared__ float tile[SHF_GPW * SHF_STRIDE];
+		const int lane = threadIdx.x, g = lane & (SHF_GPW - 1), half = lane >> 5;
+		const int g0 = blockIdx.x * SHF_GPW;
+		const bool valid = g0 + g < a.P;
+		const int idx = valid ? g0 + g : a.P - 1;
+		const int row_floats = 3 * a.M;
 		const bool sh3d = a.sh3d != 0;
 		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
 		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+		const int act_floats = min(48 * nblocks, row_floats);   // row prefix that can carry a gradient
+
+		float3 acc[3][8];
+#pragma unroll
+		for (int b = 0; b < 3; b++)
+#pragma unroll
+			for (int j = 0; j < 8; j++) acc[b][j] = make_float3(0.f, 0.f, 0.f);
 		bool any = false;
 		for (int v = 0; v < a.nviews; v++)
 		{
 			const float4 s0 = a.stages[2 * ((size_t)v * a.P + idx)];
-			any = any || (valid && (s0.x != 0.f || s0.y != 0.f || s0.z != 0.f));
-		}
-		const unsigned long long vmask = __ballot(any);
-		for (int blk = 0; blk < nblocks; blk++)
-		{
-			const int nk = (blk == 0) ? ncoef0 : 16;
-			const int first_float = 48 * blk;
-			const bool vec = a.vec_ok && nk == 16;
-			if (any)
-			{
-				// the wave-private LDS row is the accumulator: the first live view writes, the following ones add (same
-				// additions, same order as backward calls accumulating into dL_dsh view after view)
-				bool first = true;
-				for (int v = 0; v < a.nviews; v++)
-				{
-					const float4 s0 = a.stages[2 * ((size_t)v * a.P + idx)], s1 = a.stages[2 * ((size_t)v * a.P + idx) + 1];
-					const float3 dRGB = make_float3(s0.x, s0.y, s0.z);
-					if (dRGB.x == 0.f && dRGB.y == 0.f && dRGB.z == 0.f) continue;   // this view added nothing
-					float l[16];
-					sh_values(a.D, s1.x, s1.y, s1.z, !sh3d, l);
-					const float dir_t = s0.w;
-					float tk = 1.f;
-					if (blk == 1) tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
-					else if (blk == 2) tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+			const float3 dRGB = make_float3(s0.x, s0.y, s0.z);
+			if (!valid || (dRGB.x == 0.f && dRGB.y == 0.f && dRGB.z == 0.f)) continue;   // this view added nothing
+			const float4 s1 = a.stages[2 * ((size_t)v * a.P + idx) + 1];
+			any = true;
+			float l[16];
+			sh_values(a.D, s1.x, s1.y, s1.z, !sh3d, l);
 #pragma unroll
-					for (int k = 0; k < 16; k++)
+			for (int j = 0; j < 8; j++)
+			{
+				const int k = 8 * half + j;
+				const float lk = half ? l[8 + j] : l[j];
+				float basis = lk;
+				if (j == 1 && half == 0 && !sh3d && !a.analytic) basis = l[0]; // Q1
+				if (k >= ncoef0) basis = 0.f;
+				acc[0][j] = s_add(acc[0][j], s_scl(basis, dRGB));
+				if (nblocks > 1) acc[1][j] = s_add(acc[1][j], s_scl(s0.w * lk, dRGB));
+				if (nblocks > 2) acc[2][j] = s_add(acc[2][j], s_scl(s1.w * lk, dRGB));
+			}
+		}
+		const unsigned long long vmask = __ballot(any);   // bit g (and g + 32)
+		if (any)
+		{
+			float* row = tile + g * SHF_STRIDE + 24 * half;
+#pragma unroll
+			for (int b = 0; b < 3; b++)
+#pragma unroll
+				for (int j = 0; j < 8; j++)
+				{
+					row[48 * b + 3 * j] = acc[b][j].x; row[48 * b + 3 * j + 1] = acc[b][j].y; row[48 * b + 3 * j + 2] = acc[b][j].z;
+				}
+		}
+		__builtin_amdgcn_wave_barrier();
+
+		if (MODE == 1 || a.vec_ok)
+		{
+			// whole rows, float4 by float4, linearly through memory: chunk c of the wave = (Gaussian c / RC, float4 c % RC of its row)
+			const int RC = row_floats / 4, total = SHF_GPW * RC;
+			const int dg = WAVE / RC, dq = WAVE - dg * RC;
+			int cg = lane / RC, cq = lane - cg * RC;
+			for (int c0 = 0; c0 < total; c0 += SHF_BATCH * WAVE)
+			{
+				float4 pp[SHF_BATCH], mm[SHF_BATCH], vv[SHF_BATCH];
+				int og[SHF_BATCH], oq[SHF_BATCH];
+#pragma unroll
+				for (int i = 0; i < SHF_BATCH; i++)
+				{
+					og[i] = cg; oq[i] = cq;
+					cg += dg; cq += dq;
+					if (cq >= RC) { cq -= RC; cg++; }
+					const bool in = c0 + i * WAVE + lane < total && g0 + og[i] < a.P;
+					if (!in) og[i] = -1;
+					if (MODE == 1 && in)
 					{
-						if (k < nk)
+						const size_t o = (size_t)(g0 + og[i]) * row_floats + 4 * oq[i];
+						pp[i] = *reinterpret_cast<const float4*>(a.p + o);
+						mm[i] = *reinterpret_cast<const float4*>(a.m + o);
+						vv[i] = *reinterpret_cast<const float4*>(a.v + o);
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < SHF_BATCH; i++)
+				{
+					if (og[i] < 0) continue;
+					const int e0 = 4 * oq[i];
+					const bool live = ((vmask >> og[i]) & 1ull) && e0 < act_floats;
+					const float* t = tile + og[i] * SHF_STRIDE + e0;
+					float ge[4] = { 0.f, 0.f, 0.f, 0.f };
+					if (live) { ge[0] = t[0]; ge[1] = t[1]; ge[2] = t[2]; ge[3] = t[3]; }
+					const size_t o = (size_t)(g0 + og[i]) * row_floats + e0;
+					if (MODE == 1)
+					{
+						float pe[4] = { pp[i].x, pp[i].y, pp[i].z, pp[i].w }, me[4] = { mm[i].x, mm[i].y, mm[i].z, mm[i].w };
+						float ve[4] = { vv[i].x, vv[i].y, vv[i].z, vv[i].w };
+#pragma unroll
+						for (int e = 0; e < 4; e++)
 						{
-							float basis = l[k];
-							if (blk == 0 && k == 1 && !sh3d && s1.w == 0.f) basis = l[0]; // Q1 (s1.w: the view ran with analytic_sh_grad)
-							float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
-							if (!first) d = s_add(s_ld3(row, k), d);
-							row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
+							// the DC coefficient (first 3 floats of the row) has its own learning rate (gaussian_model.py:339-340)
+							const float lr = (e0 == 0 && e < 3) ? a.k.lr_head_bc1 : a.k.lr_bc1;
+							adam_update(pe[e], me[e], ve[e], ge[e], lr, a.k.b1, a.k.b2, a.k.eps, a.k.inv_sqrt_bc2);
+						}
+						*reinterpret_cast<float4*>(a.m + o) = make_float4(me[0], me[1], me[2], me[3]);
+						*reinterpret_cast<float4*>(a.v + o) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+						*reinterpret_cast<float4*>(a.p + o) = make_float4(pe[0], pe[1], pe[2], pe[3]);
+						if (a.dL_dsh) *reinterpret_cast<float4*>(a.dL_dsh + o) = make_float4(ge[0], ge[1], ge[2], ge[3]);
+					}
+					else
+					{
+						float4* d = reinterpret_cast<float4*>(a.dL_dsh + o);
+						if (!a.accum) *d = make_float4(ge[0], ge[1], ge[2], ge[3]);
+						else if (live)
+						{
+							const float4 old = *d;
+							*d = make_float4(old.x + ge[0], old.y + ge[1], old.z + ge[2], old.w + ge[3]);
 						}
 					}
-					first = false;
 				}
 			}
-			__builtin_amdgcn_wave_barrier();
-			if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
-			else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
-			__builtin_amdgcn_wave_barrier();
 		}
-		if (!a.accum)
+		else
 		{
-			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
-			const int rest = (int)row_floats - written;
-			if (rest > 0) tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written, rest > 48 ? 48 : rest, 0ull, lane, false);
-			for (int done = 48; done < rest; done += 48)
-				tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written + done, min(48, rest - done), 0ull, lane, false);
+			// any row length / alignment, float by float
+			const int total = SHF_GPW * row_floats;
+			const int dg = WAVE / row_floats, dpos = WAVE - dg * row_floats;
+			int cg = lane / row_floats, pos = lane - cg * row_floats;
+			for (int e = lane; e < total; e += WAVE)
+			{
+				if (g0 + cg < a.P)
+				{
+					const bool live = ((vmask >> cg) & 1ull) && pos < act_floats;
+					float* d = a.dL_dsh + (size_t)(g0 + cg) * row_floats + pos;
+					if (!a.accum) *d = live ? tile[cg * SHF_STRIDE + pos] : 0.f;
+					else if (live) *d += tile[cg * SHF_STRIDE + pos];
+				}
+				cg += dg; pos += dpos;
+				if (pos >= row_floats) { pos -= row_floats; cg++; }
+			}
 		}
 	}
 
-	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, float time_duration, int nviews,
+	static void fill_flush_args(ShFlushArgs& a, int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, int analytic, int nviews,
+	                            const float* stages, float* dL_dsh)
+	{
+		a.P = P; a.D = D; a.D_t = D_t; a.M = M; a.nviews = nviews;
+		a.sh3d = (gaussian_dim == 3 || force_sh_3d) ? 1 : 0;
+		a.analytic = analytic; a.accum = 0;
+		a.vec_ok = ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0 && (3 * M) % 4 == 0) ? 1 : 0;
+		a.stages = reinterpret_cast<const float4*>(stages);
+		a.dL_dsh = dL_dsh;
+		a.p = a.m = a.v = nullptr;
+		a.k = AdamScalars{};
+	}
+
+	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, int analytic, int nviews,
 	                           const float* stages, float* dL_dsh, int accumulate, hipStream_t stream)
 	{
 		if (P <= 0 || M <= 0 || nviews <= 0) return hipSuccess;
 		ShFlushArgs a;
-		a.P = P; a.D = D; a.D_t = D_t; a.M = M; a.nviews = nviews;
-		a.sh3d = (gaussian_dim == 3 || force_sh_3d) ? 1 : 0;
-		a.vec_ok = ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0 && (3 * M) % 4 == 0) ? 1 : 0;
-		a.accum = accumulate; a.time_duration = time_duration;
-		a.stages = reinterpret_cast<const float4*>(stages);
-		a.dL_dsh = dL_dsh;
-		hipLaunchKernelGGL(sh_flush_kernel, dim3(div_up(P, SHB_GPW)), dim3(WAVE), 0, stream, a);
+		fill_flush_args(a, P, D, D_t, M, gaussian_dim, force_sh_3d, analytic, nviews, stages, dL_dsh);
+		a.accum = accumulate;
+		hipLaunchKernelGGL(sh_flush_kernel<0>, dim3(div_up(P, SHF_GPW)), dim3(WAVE), 0, stream, a);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_sh_adam(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, int analytic, int nviews,
+	                          const float* stages, float* params, float* exp_avg, float* exp_avg_sq, float* dL_dsh,
+	                          const AdamScalars& k, hipStream_t stream)
+	{
+		if (P <= 0 || M <= 0) return hipSuccess;
+		const uintptr_t align = reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(exp_avg) |
+		                        reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(dL_dsh);
+		// the DC learning rate is applied to the first 3 floats of a row: rows must start on a float4 boundary
+		if (nviews <= 0 || (3 * M) % 4 != 0 || (align & 15) != 0) return hipErrorInvalidValue;
+		ShFlushArgs a;
+		fill_flush_args(a, P, D, D_t, M, gaussian_dim, force_sh_3d, analytic, nviews, stages, dL_dsh);
+		a.p = params; a.m = exp_avg; a.v = exp_avg_sq; a.k = k;
+		hipLaunchKernelGGL(sh_flush_kernel<1>, dim3(div_up(P, SHF_GPW)), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
 	}
 }

@@ -31,6 +31,11 @@ def set_analytic_sh_gradients(on: bool) -> None:
     _ANALYTIC_SH_GRAD = bool(on)
 
 
+def analytic_sh_gradients() -> bool:
+    """The mode set_analytic_sh_gradients selected (callers of fdgs_sh_flush / fdgs_adam_step_sh pass it on)."""
+    return _ANALYTIC_SH_GRAD
+
+
 def _is_given(t) -> bool:
     return t is not None and t.numel() > 0
 

@@ -19,13 +19,20 @@ import torch
 
 from . import _capi
 from .fused import raw_backward, raw_forward, raw_settings
+from .gaussian_renderer import diff_gaussian_rasterization as _dgr
 from .loss import l1_ssim_grad, l1_ssim_loss
 from .train_host import allreduce_and_step, allreduce_sh_begin
 
 
 class StepPipeline:
-    def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True):
+    def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
+                 fuse_sh_adam: bool = True):
+        """``fuse_sh_adam``: on one rank with B > 1 views per step, the SH coefficients are updated straight from the views'
+        staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
+        the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
+        bucket is what the all-reduce sums)."""
         self.model, self.opt, self.world, self.lam = model, optimizer, int(world_size), float(lambda_dssim)
+        self.fuse_sh_adam = bool(fuse_sh_adam)
         dev = model.flat.device
         self.dev = dev
         # (Tried and dropped, with measurements on MI355X: a high-priority F stream and a CU-masked B stream change
@@ -60,6 +67,7 @@ class StepPipeline:
         # deferred SH gradient: with B > 1 views per step every view stages the 7 numbers it contributes to dL_dsh and ONE
         # flush per step writes the 3 M floats per Gaussian (instead of a read-modify-write of them per view)
         defer_sh = B > 1
+        fuse = defer_sh and self.fuse_sh_adam and self.world == 1
         if defer_sh and (self._sh_stage is None or self._sh_stage.shape[0] != B or self._sh_stage.shape[1] != m.P):
             with torch.cuda.stream(self.sB):
                 self._sh_stage = torch.empty((B, m.P, 8), dtype=torch.float32, device=self.dev)
@@ -79,11 +87,11 @@ class StepPipeline:
                 # last view of the step on several ranks: the SH gradients (88 % of the bucket) are final once this view's
                 # SH backward has run -- their all-reduce starts there and travels while the geometry backward runs
                 after_sh = None
-                if b == B - 1 and (defer_sh or self.world > 1):
+                if b == B - 1 and ((defer_sh and not fuse) or self.world > 1):
                     def after_sh():
                         if defer_sh:
                             _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
-                                           rs.force_sh_3d, rs.time_duration)
+                                           rs.force_sh_3d, _dgr.analytic_sh_gradients())
                         if self.world > 1:
                             sh_handle.append(allreduce_sh_begin(m, self.world))
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
@@ -98,7 +106,16 @@ class StepPipeline:
             losses.append(loss)
         with torch.cuda.stream(self.sB):
             # the losses were scaled by 1 / (B * world): SUM = mean; Adam on chunk k overlaps the all-reduce of chunk k+1
-            allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None)
+            if fuse:
+                self.opt.step_count += 1
+                if self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()):
+                    self.opt.step_range(0, m.offsets["_features"][0])
+                else:   # layout the fused kernel does not take: the two passes
+                    _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
+                                   rs.force_sh_3d, _dgr.analytic_sh_gradients())
+                    self.opt.step_range(0, m.flat.numel())
+            else:
+                allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)
         self.sF.wait_stream(self.sB)

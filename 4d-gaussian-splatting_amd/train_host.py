@@ -231,6 +231,24 @@ class FlatAdam:
         m.flat[sl].sub_(self._lr_vec[sl] / bc1 * (self.exp_avg[sl] / denom))
 
 
+    @torch.no_grad()
+    def step_sh_staged(self, stages: torch.Tensor, rs, analytic_sh_grad: bool = False, write_grad: bool = False) -> bool:
+        """The update of the ``_features`` segment for the CURRENT step_count, with its gradient taken from the staged views
+        of the deferred SH backward (``stages`` [B, P, 8], csrc/sh_bwd.hip sh_adam_kernel): fdgs_sh_flush + step_range on
+        that segment in one pass, without dL_dsh travelling through memory.  ``rs``: the views' raster settings (SH degrees,
+        gaussian_dim ...).  ``write_grad``: also leave the summed gradient in ``_features.grad``.  Returns False -- nothing
+        done -- when the layout is not supported (rows not whole float4s / segment not 16-byte aligned)."""
+        from . import _capi
+        m = self.model
+        b, e = m.offsets["_features"]
+        seg = next(s for s in self.segments if s["begin"] == b and s["end"] == e)
+        shape = m.params["_features"].shape
+        return _capi.adam_step_sh(m.flat[b:e].view(shape), self.exp_avg[b:e].view(shape), self.exp_avg_sq[b:e].view(shape), stages,
+                                  rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim, rs.force_sh_3d, analytic_sh_grad,
+                                  seg["lr"], seg["lr_head"], self.betas[0], self.betas[1], self.eps, self.step_count,
+                                  dL_dsh=m.params["_features"].grad if write_grad else None)
+
+
 def make_optimizer(model: GaussianParams) -> FlatAdam:
     return FlatAdam(model)
 

@@ -166,8 +166,9 @@ typedef struct fdgs_backward_out
 	                             1: the caller guarantees it is all zero on entry (a persistent buffer, zeroed once) and
 	                                the call leaves it all zero on exit: the last kernel re-zeroes what it has read */
 	float* sh_stage;          /* NULL: dL_dsh is written / accumulated by this call.  Otherwise [P,8] floats of scratch owned by the
-	                             caller: DEFERRED SH gradient -- the call leaves dL_dsh alone and stores, per Gaussian, the 7
-	                             numbers this view contributes through (its dL_dRGB, the view direction, the time offset);
+	                             caller: DEFERRED SH gradient -- the call leaves dL_dsh alone and stores, per Gaussian, the 8
+	                             numbers this view contributes through (its dL_dRGB, the view direction, the cosine factors of
+	                             the two time blocks);
 	                             fdgs_sh_flush turns the stages of all views of an optimizer step into dL_dsh in one pass. */
 	int32_t stage_mask;       /* 0 (or 3): the whole backward.  1: blend backward + SH backward only -- dL_dsh is final when
 	                             they have run; 2: the geometry backward only (must follow a call with 1 on the same
@@ -190,8 +191,8 @@ int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,
  * in view order, of basis(direction, time) (x) dL_dRGB -- the same additions in the same order as backward calls that
  * accumulate into dL_dsh view after view, with 1/3 of their memory traffic at 4 views.  stages: [num_views,P,8] floats, the
  * sh_stage buffers of the views back to back.  accumulate != 0 adds to dL_dsh instead of overwriting it.
- * D, D_t, M, gaussian_dim, force_sh_3d, time_duration as in fdgs_scene. */
-int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d, float time_duration,
+ * D, D_t, M, gaussian_dim, force_sh_3d, analytic_sh_grad as in the fdgs_scene of the staged views (one value for all of them). */
+int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d, int32_t analytic_sh_grad,
                   int32_t num_views, const float* stages, float* dL_dsh, int32_t accumulate, void* stream);
 
 /* present[i] = view-space z of means3D[i] > 0.2 (checkFrustum, rasterizer_impl.cu:54-67). */
@@ -296,6 +297,18 @@ typedef struct fdgs_adam_segment
 int fdgs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                    const fdgs_adam_segment* segments, int32_t num_segments,
                    float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* Adam over the SH coefficients [P,M,3] with the gradient taken straight from the staged views of the deferred SH backward
+ * (fdgs_backward_out.sh_stage): fdgs_sh_flush + fdgs_adam_step on that segment in one pass, without the 12 M bytes per
+ * Gaussian of dL_dsh going out to memory and coming back.  params / exp_avg / exp_avg_sq point at the [P,M,3] segment; the
+ * first 3 floats of every row (the DC coefficient, scene/gaussian_model.py:339) use lr_dc, the others lr.  dL_dsh: NULL, or
+ * [P,M,3] that also receives the summed gradient (bit-identical to fdgs_sh_flush).  The update is bit-identical to
+ * fdgs_sh_flush followed by fdgs_adam_step.  Needs rows of whole float4s (3 M % 4 == 0) and 16-byte aligned arrays:
+ * FDGS_ERR_INVALID_ARG otherwise (the caller falls back to the two calls). */
+int fdgs_adam_step_sh(float* params, float* exp_avg, float* exp_avg_sq, float* dL_dsh,
+                      int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian_dim, int32_t force_sh_3d,
+                      int32_t analytic_sh_grad, int32_t num_views, const float* stages,
+                      float lr, float lr_dc, float beta1, float beta2, float eps, int32_t step, void* stream);
 
 /* ---- adjacent row: densification / pruning of the flat-bucket model --------------
  * Replaces the boolean-mask gathers and torch.cat calls of scene/gaussian_model.py:391-610 (densify_and_clone,

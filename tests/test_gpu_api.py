@@ -251,14 +251,15 @@ def test_gradient_accumulation_over_views(gpu_device):
     assert (err > 1e-4 * scale).float().mean().item() <= 1e-4 and err.max().item() <= 1e-2 * scale, err.max().item()
 
 
-def test_deferred_sh_gradient_matches_accumulation(gpu_device):
+@pytest.mark.parametrize("D,D_t,sh3d", [(3, 2, False), (3, 1, False), (3, 0, False), (2, 0, True), (0, 0, True)])
+def test_deferred_sh_gradient_matches_accumulation(gpu_device, D, D_t, sh3d):
     """fdgs_backward_out.sh_stage + fdgs_sh_flush (one write of dL_dsh per optimizer step) against backward calls that
     accumulate dL_dsh view after view.  The flush performs the same additions in the same order; what differs between the
     two runs compared here is only the run-to-run noise of the blend backward's float atomics in dL_dRGB (1e-7 relative),
     the same for every other gradient, which the mode does not touch."""
     from fdgs import _capi, train_host
     from fdgs.fused import raw_backward, raw_forward, raw_settings
-    cfg = synth.SceneConfig("defer", 7000, 208, 160, 3, 2, 0.03, 10.0, True, 4, False)
+    cfg = synth.SceneConfig("defer", 7000, 208, 160, D, D_t, 0.03, 10.0, True, 4, sh3d)
     scene = synth.make_scene(cfg, seed=21)
     bg = torch.zeros(3, device=gpu_device)
     pipe = train_host.PipelineFlags()
@@ -278,7 +279,7 @@ def test_deferred_sh_gradient_matches_accumulation(gpu_device):
             raw_backward(rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img,
                          ups[b], None, None, None, sink, b > 0, sh_stage=stage[b] if deferred else None)
         if deferred:
-            _capi.sh_flush(stage, sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim, rs.force_sh_3d, rs.time_duration)
+            _capi.sh_flush(stage, sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim, rs.force_sh_3d)
         torch.cuda.synchronize()
         return m
     a, d = run(False), run(True)
@@ -292,8 +293,59 @@ def test_deferred_sh_gradient_matches_accumulation(gpu_device):
         assert err <= (1e-5 if n == "_features" else 1e-4) * s, (n, err, s)   # the others: atomics noise through the covariance chain
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_step_pipeline_matches_autograd_step(gpu_device, overlap):
+@pytest.mark.parametrize("D,D_t,M,sh3d,analytic", [(3, 2, 48, False, False), (3, 1, 48, False, True), (3, 0, 16, False, False),
+                                                   (2, 0, 16, True, False), (0, 0, 16, True, False), (3, 2, 64, False, False),
+                                                   (1, 0, 4, True, False), (3, 2, 16, False, False)])
+def test_sh_adam_fused_is_flush_plus_adam(gpu_device, D, D_t, M, sh3d, analytic):
+    """fdgs_adam_step_sh (SH gradient built from the staged views and consumed by Adam in one kernel) against fdgs_sh_flush
+    followed by fdgs_adam_step on the same stages: gradient, parameters and both moments bit-identical -- over two steps, with
+    Gaussians no view touched (g = 0: the moments still decay), inactive coefficient blocks and the DC learning rate."""
+    from fdgs import _capi
+    P, B = 4 * 1237, 3
+    gen = torch.Generator(device="cpu").manual_seed(100 + D + 7 * D_t + M)
+    stages = torch.randn(B, P, 8, generator=gen)
+    stages[:, :, 3] = torch.rand(B, P, generator=gen) * 2 - 1    # cosine factors of the two time blocks
+    stages[:, :, 7] = torch.rand(B, P, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(stages[:, :, 4:7], dim=-1)
+    stages[:, :, 4:7] = d
+    dead = torch.rand(B, P, generator=gen) < 0.4                 # views that did not touch the Gaussian
+    stages[:, :, 0:3][dead] = 0.0
+    stages = stages.to(gpu_device).contiguous()
+    lr, lr_dc, b1, b2, eps = 1.25e-4, 2.5e-3, 0.9, 0.999, 1e-15
+
+    def fresh():
+        g = torch.Generator(device="cpu").manual_seed(5)
+        p = torch.randn(P, M, 3, generator=g).to(gpu_device)
+        m = (0.01 * torch.randn(P, M, 3, generator=g)).to(gpu_device)
+        v = (1e-4 * torch.rand(P, M, 3, generator=g)).to(gpu_device)
+        return p, m, v
+    pa, ma, va = fresh()
+    pf, mf, vf = fresh()
+    ga = torch.full((P, M, 3), float("nan"), device=gpu_device)
+    gf = torch.full((P, M, 3), float("nan"), device=gpu_device)
+    seg = (_capi.FdgsAdamSegment * 1)(_capi.FdgsAdamSegment(0, P * M * 3, lr, lr_dc, M * 3, 3))
+    for step in (1, 2):
+        _capi.sh_flush(stages, ga, D, D_t, 3 if sh3d else 4, sh3d, analytic)
+        rc = _capi.lib.fdgs_adam_step(pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), P * M * 3, seg, 1, b1, b2, eps, step,
+                                      _capi.current_stream_handle(gpu_device))
+        assert rc == 0
+        assert _capi.adam_step_sh(pf, mf, vf, stages, D, D_t, 3 if sh3d else 4, sh3d, analytic, lr, lr_dc, b1, b2, eps, step, dL_dsh=gf)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ga).all() and torch.equal(ga, gf)
+        assert (ga != 0).float().mean().item() > 0.01
+        assert torch.equal(ma, mf) and torch.equal(va, vf) and torch.equal(pa, pf)
+    # without the gradient output; and a layout it refuses (row not a multiple of 16 coefficients) is reported, not half done
+    pg, mg, vg = fresh()
+    for step in (1, 2):
+        assert _capi.adam_step_sh(pg, mg, vg, stages, D, D_t, 3 if sh3d else 4, sh3d, analytic, lr, lr_dc, b1, b2, eps, step)
+    torch.cuda.synchronize()
+    assert torch.equal(pg, pf) and torch.equal(mg, mf) and torch.equal(vg, vf)
+    podd = torch.zeros(P, 1, 3, device=gpu_device)
+    assert not _capi.adam_step_sh(podd, podd.clone(), podd.clone(), stages, 0, 0, 3, True, False, lr, lr_dc, b1, b2, eps, 1)
+
+
+@pytest.mark.parametrize("overlap,fuse", [(True, True), (False, True), (True, False)])
+def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse):
     """fdgs.pipeline.StepPipeline (explicit forward / fused loss / backward on two HIP streams, no autograd) performs
     the same optimizer step as render_raw + fused_l1_ssim + backward() + Adam on one stream."""
     from fdgs import train_host
@@ -321,7 +373,7 @@ def test_step_pipeline_matches_autograd_step(gpu_device, overlap):
         oa.step()
 
     mp = train_host.GaussianParams(scene, gpu_device)
-    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap)
+    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap, fuse_sh_adam=fuse)
     got_losses = []
     for _ in range(2):
         results, losses = sp.step(cams, gts, pipe, bg)
@@ -330,7 +382,9 @@ def test_step_pipeline_matches_autograd_step(gpu_device, overlap):
     torch.cuda.synchronize()
     np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-5, atol=1e-6)
     # the gradients of the last step (float atomics: summation order differs run to run) and the parameters after two steps
-    gerr = (mp.flat_grad - ma.flat_grad).abs()
+    # (fuse_sh_adam: the SH gradient goes from the views' stages straight into Adam and is not materialised in the bucket)
+    n_cmp = mp.offsets["_features"][0] if fuse else mp.flat.numel()
+    gerr = (mp.flat_grad[:n_cmp] - ma.flat_grad[:n_cmp]).abs()
     gscale = max(1e-6, ma.flat_grad.abs().max().item())
     assert gerr.max().item() <= 1e-3 * gscale, (gerr.max().item(), gscale)
     perr = (mp.flat - ma.flat).abs().max().item()
