@@ -195,12 +195,12 @@ namespace fdgs
 		// One queue entry against this lane's pixel, after the packed head: d = mean2D - pixel, power, G = exp(power), alpha;
 		// colour (cr, cg, cb), depth, flow of the entry; active = this pixel takes part; eid = Gaussian id.
 		auto entry = [&](const float dx, const float dy, const float power, const float G, const float alpha, const float cr, const float cg,
-		                 const float cb, const float cdepth, const float cfx, const float cfy, const bool active, const uint32_t eid) __attribute__((always_inline))
+		                 const float cb, const float cdepth, const float cfx, const float cfy, const lanemask active, const uint32_t eid) __attribute__((always_inline))
 		{
 			// Branch-free: a lane that skips this entry runs the same instructions with
 			// alpha = G = 0, which leaves T and the recurrence unchanged and makes all 12 products zero.
-			const float alpha_e = active ? alpha : 0.0f;
-			const float G_e = active ? G : 0.0f;
+			const float alpha_e = mask_select(active, alpha, 0.0f);
+			const float G_e = mask_select(active, G, 0.0f);
 			const float inv = __builtin_amdgcn_rcpf(1.f - alpha_e);
 			T = T * inv;
 			const float dchannel_dcolor = alpha_e * T;
@@ -245,11 +245,11 @@ namespace fdgs
 		// Both entries of a pair have contributing pixels (the common case): the same arithmetic as `entry` twice, but
 		// everything that is not part of the sequential T / S recurrences runs packed on the two entries.
 		auto entry_pair = [&](const v2f dx, const v2f dy, const v2f G, const float alpha0, const float alpha1, const v2f cr, const v2f cg,
-		                      const v2f cb, const v2f cdepth, const v2f cfx, const v2f cfy, const bool act0, const bool act1,
+		                      const v2f cb, const v2f cdepth, const v2f cfx, const v2f cfy, const lanemask act0, const lanemask act1,
 		                      const uint32_t eid0, const uint32_t eid1) __attribute__((always_inline))
 		{
-			const v2f alpha_e = { act0 ? alpha0 : 0.0f, act1 ? alpha1 : 0.0f };
-			const v2f G_e = { act0 ? G.x : 0.0f, act1 ? G.y : 0.0f };
+			const v2f alpha_e = { mask_select(act0, alpha0, 0.0f), mask_select(act1, alpha1, 0.0f) };
+			const v2f G_e = { mask_select(act0, G.x, 0.0f), mask_select(act1, G.y, 0.0f) };
 			const v2f om = 1.0f - alpha_e;
 			const v2f inv = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };
 			const float T0 = T * inv.x, T1 = T0 * inv.y;
@@ -340,10 +340,10 @@ namespace fdgs
 				const v2f G = { __builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y) };
 				const v2f al = op * G;
 				const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
-				// one predicate instead of the reference's three nested tests (backward.cu:1040-1054)
-				const bool act0 = ((int)pp.x < last_contributor) && !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
-				const bool act1 = ((int)pp.y < last_contributor) && !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
-				const bool any0 = __ballot(act0) != 0ull, any1 = __ballot(act1) != 0ull;
+				// one predicate instead of the reference's three nested tests (backward.cu:1040-1054), as a lane mask
+				const lanemask act0 = mask_of((int)pp.x < last_contributor) & mask_of(!(power.x > 0.0f)) & mask_of(!(alpha0 < 1.0f / 255.0f));
+				const lanemask act1 = mask_of((int)pp.y < last_contributor) & mask_of(!(power.y > 0.0f)) & mask_of(!(alpha1 < 1.0f / 255.0f));
+				const bool any0 = act0 != 0ull, any1 = act1 != 0ull;
 				if (any0 && any1)
 					entry_pair(dx, dy, G, alpha0, alpha1, v2f{ Q3.x, Q3.y }, v2f{ Q3.z, Q3.w }, v2f{ Q4.x, Q4.y }, v2f{ Q4.z, Q4.w },
 					           v2f{ Q5.x, Q5.y }, v2f{ Q5.z, Q5.w }, act0, act1, ii.x, ii.y);

@@ -23,6 +23,25 @@ namespace fdgs
 
 	__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+	// Lane predicates as wave masks.  A predicate that is the AND of several compares costs the compiler a
+	// v_cndmask(0/1) + v_cmp_ne pair whenever a ballot of it is needed; keeping the compares as 64-bit masks (one v_cmp each,
+	// combined on the scalar unit) and selecting with the mask directly avoids both.  Uniform control flow only (all 64 lanes active).
+	typedef unsigned long long lanemask;
+	__device__ __forceinline__ lanemask mask_of(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+	// mask bit set ? a : b
+	__device__ __forceinline__ float mask_select(lanemask m, float a, float b)
+	{
+		float r;
+		asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+		return r;
+	}
+	__device__ __forceinline__ uint32_t mask_select(lanemask m, uint32_t a, uint32_t b)
+	{
+		uint32_t r;
+		asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+		return r;
+	}
+
 	struct BlockId { int tile, sub; };
 	// Workgroup id -> (tile, 8x8 sub-block).  Workgroups are dealt round-robin to the 8 XCDs
 	// (id % 8); give each XCD a contiguous band of tiles and keep the 4 sub-blocks of a tile on

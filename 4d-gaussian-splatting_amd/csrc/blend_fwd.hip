@@ -48,14 +48,14 @@ namespace fdgs
 		const int n = (int)(range.y - range.x);
 		const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-		bool done = !inside;
+		lanemask done = mask_of(!inside);   // pixels that take no further contribution
 		float T = 1.0f;
 		uint32_t last_contributor = 0;
 		v2f acc_r = { 0.f, 0.f }, acc_g = acc_r, acc_b = acc_r, acc_d = acc_r, acc_fx = acc_r, acc_fy = acc_r;
 
 		for (int base = 0; base < n; base += WAVE)
 		{
-			if (__ballot(!done) == 0ull) break; // all 64 pixels saturated
+			if (done == ~0ull) break; // all 64 pixels saturated
 			const int pos = base + lane;
 			bool keep = false;
 			uint32_t id = 0;
@@ -111,16 +111,18 @@ namespace fdgs
 				const v2f al = op * v2f{ __builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y) };
 				const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
 				v2f w;
+				// forward.cu:588-597 on lane masks: valid = not finished, power <= 0, alpha >= 1/255; a valid entry that would take T
+				// below 1e-4 finishes the pixel (and is not counted), any other valid entry contributes
 #define FDGS_BLEND_STEP(alpha, pw, pos1, wout)                                                            \
 				{                                                                                         \
 					const float test_T = T * (1.0f - alpha);                                              \
-					const bool valid = !done && !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);                \
-					const bool stop = valid && (test_T < 0.0001f);                                        \
-					const bool contrib = valid && !stop;                                                  \
-					wout = contrib ? alpha * T : 0.0f;                                                    \
-					T = contrib ? test_T : T;                                                             \
-					last_contributor = contrib ? pos1 : last_contributor;                                 \
-					done = done || stop;                                                                  \
+					const lanemask valid = ~done & mask_of(!(pw > 0.0f)) & mask_of(!(alpha < 1.0f / 255.0f)); \
+					const lanemask low = mask_of(test_T < 0.0001f);                                       \
+					const lanemask contrib = valid & ~low;                                                \
+					wout = mask_select(contrib, alpha * T, 0.0f);                                         \
+					T = mask_select(contrib, test_T, T);                                                  \
+					last_contributor = mask_select(contrib, pos1, last_contributor);                      \
+					done |= valid & low;                                                                  \
 				}
 				FDGS_BLEND_STEP(alpha0, power.x, pp.x, w.x)
 				FDGS_BLEND_STEP(alpha1, power.y, pp.y, w.y)
@@ -131,7 +133,7 @@ namespace fdgs
 				acc_d = __builtin_elementwise_fma(v2f{ Q4.z, Q4.w }, w, acc_d);
 				acc_fx = __builtin_elementwise_fma(v2f{ Q5.x, Q5.y }, w, acc_fx);
 				acc_fy = __builtin_elementwise_fma(v2f{ Q5.z, Q5.w }, w, acc_fy);
-				if (__ballot(!done) == 0ull) break;
+				if (done == ~0ull) break;
 			}
 			__syncthreads(); // the queue is rewritten by the next chunk
 		}
