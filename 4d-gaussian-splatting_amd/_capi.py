@@ -16,7 +16,8 @@ import os
 import torch  # must be imported before libfdgs.so so both share one HIP runtime (same SONAME)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfdgs.so")
+# FDGS_LIB: another build of the same library (A/B timing of kernel variants, tools/ab_build.sh); default: the in-tree build
+LIB_PATH = os.environ.get("FDGS_LIB") or os.path.join(_HERE, "csrc", "libfdgs.so")
 
 FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
 
