@@ -4,12 +4,16 @@
 // backward.cu:20-139, 144-481): every thread reads its own 12*M bytes of coefficients and writes its own
 // 12*M bytes of dL_dsh with a 12*M-byte stride between threads.  At M = 48 that is 576 B in and 576 B out per
 // Gaussian -- 80 % of all bytes the whole per-Gaussian backward moves -- so it gets its own kernel here:
-//   * a wave owns 32 consecutive Gaussians (64 measured 1 % slower: half the waves in flight); their rows are staged block by block (16
-//     coefficients = 192 B per Gaussian) through a wave-private LDS tile with fully coalesced dwordx4 loads;
-//   * each lane then walks ITS Gaussian's row in LDS (row stride 49 floats: conflict free), accumulates the
+//   * every output of the kernel is linear in the Gaussian's dL_dRGB, and a Gaussian that is visible but contributed to no
+//     pixel (occluded, or too faint everywhere: 58 % of the visible ones on C3) has dL_dRGB == 0 exactly.  A wave first
+//     scans a span of 128 consecutive Gaussians and ballot-compacts the LIVE ones (those with a colour gradient) into a list;
+//     the others only get their zeros (accumulator words 12..15, the stage record / the dL_dsh row);
+//   * the live Gaussians are then taken 64 at a time, one per lane: their rows are staged block by block (16 coefficients
+//     = 192 B per Gaussian) through a wave-private LDS tile with coalesced dwordx4 loads (gathered rows, contiguous runs);
+//   * each lane walks ITS Gaussian's row in LDS (row stride 49 floats: conflict free), accumulates the
 //     direction / time dot products in registers and overwrites the row with dL_dsh;
-//   * the tile is written back with coalesced dwordx4 stores (zeros for culled Gaussians, so dL_dsh never
-//     needs a memset).
+//   * the tile is written back with coalesced dwordx4 stores.
+//   (One lane per Gaussian of the span instead -- the first version -- left 13 of 64 lanes with work in the evaluation.)
 // The four numbers the geometry backward needs from here -- the mean gradient through the view direction
 // (3) and the time gradient (1) -- travel in the spare words 12..15 of the Gaussian's packed accumulator record.
 //
@@ -26,11 +30,8 @@ namespace fdgs
 {
 	constexpr int SHB_STRIDE = 49;   // LDS row stride in floats (odd: lane-per-row access is conflict free)
 	constexpr int SHB_CH = 12;       // float4 chunks per Gaussian and block (16 coefficients x 3 / 4)
-#ifndef FDGS_SHB_GPW
-#define FDGS_SHB_GPW 32
-#endif
-	constexpr int SHB_GPW = FDGS_SHB_GPW;   // Gaussians per wave: 32 halves the LDS tile (6.3 KB) -> twice the waves per CU in flight
-	constexpr int SHB_IT = SHB_CH * SHB_GPW / WAVE;  // float4 per lane and block
+	constexpr int SHB_SPAN = 128;    // consecutive Gaussians a wave scans for live ones
+	constexpr int SHB_ROWS = WAVE;   // live Gaussians evaluated per round, one per lane (tile: 12.5 KB)
 
 	struct ShBwdArgs
 	{
@@ -90,42 +91,45 @@ namespace fdgs
 		}
 	}
 
-	// ---- tile <-> global, coalesced ----
-	__device__ __forceinline__ void tile_load16(float* __restrict__ tile, const float* __restrict__ src, int g0, int P, size_t row_floats,
-	                                            int first_float, unsigned long long mask, int lane)
+	// ---- tile <-> global, coalesced; tile row r belongs to Gaussian g0 + list[r], r < nrows ----
+	constexpr int SHB_BATCH = 6;     // float4 per lane in flight while staging (2 batches per block)
+	__device__ __forceinline__ void rows_load16(float* __restrict__ tile, const float* __restrict__ src, const uint32_t* list, int nrows,
+	                                            int g0, size_t row_floats, int first_float, int lane)
 	{
-		float4 v[SHB_IT];
 #pragma unroll
-		for (int i = 0; i < SHB_IT; i++)
+		for (int b = 0; b < SHB_CH * SHB_ROWS / WAVE / SHB_BATCH; b++)
 		{
-			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
-			const bool ok = g0 + g < P && ((mask >> g) & 1ull);
-			v[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(g0 + g) * row_floats + first_float + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-		}
+			float4 v[SHB_BATCH];
 #pragma unroll
-		for (int i = 0; i < SHB_IT; i++)
-		{
-			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
-			float* d = tile + g * SHB_STRIDE + 4 * q;
-			d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+			for (int i = 0; i < SHB_BATCH; i++)
+			{
+				const int c = (b * SHB_BATCH + i) * WAVE + lane, r = c / SHB_CH, q = c - r * SHB_CH;
+				v[i] = r < nrows ? *reinterpret_cast<const float4*>(src + (size_t)(g0 + list[r]) * row_floats + first_float + 4 * q)
+				                 : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+#pragma unroll
+			for (int i = 0; i < SHB_BATCH; i++)
+			{
+				const int c = (b * SHB_BATCH + i) * WAVE + lane, r = c / SHB_CH, q = c - r * SHB_CH;
+				float* d = tile + r * SHB_STRIDE + 4 * q;
+				d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+			}
 		}
 	}
-	__device__ __forceinline__ void tile_store16(const float* __restrict__ tile, float* __restrict__ dst, int g0, int P, size_t row_floats,
-	                                             int first_float, unsigned long long mask, int lane, bool accum)
+	__device__ __forceinline__ void rows_store16(const float* __restrict__ tile, float* __restrict__ dst, const uint32_t* list, int nrows,
+	                                             int g0, size_t row_floats, int first_float, int lane, bool accum)
 	{
 #pragma unroll
-		for (int i = 0; i < SHB_IT; i++)
+		for (int i = 0; i < SHB_CH * SHB_ROWS / WAVE; i++)
 		{
-			const int c = i * WAVE + lane, g = c / SHB_CH, q = c - g * SHB_CH;
-			if (g0 + g < P)
+			const int c = i * WAVE + lane, r = c / SHB_CH, q = c - r * SHB_CH;
+			if (r < nrows)
 			{
-				const float* s = tile + g * SHB_STRIDE + 4 * q;
-				const bool live = (mask >> g) & 1ull;
-				float4* d = reinterpret_cast<float4*>(dst + (size_t)(g0 + g) * row_floats + first_float + 4 * q);
-				float4 v = live ? make_float4(s[0], s[1], s[2], s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+				const float* t = tile + r * SHB_STRIDE + 4 * q;
+				float4* d = reinterpret_cast<float4*>(dst + (size_t)(g0 + list[r]) * row_floats + first_float + 4 * q);
+				float4 v = make_float4(t[0], t[1], t[2], t[3]);
 				if (accum)
 				{
-					if (!live) continue; // adding zero
 					const float4 o = *d;
 					v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
 				}
@@ -134,35 +138,43 @@ namespace fdgs
 		}
 	}
 	// generic (any float count per row / alignment)
-	__device__ __forceinline__ void tile_load_any(float* __restrict__ tile, const float* __restrict__ src, int g0, int P, size_t row_floats,
-	                                              int first_float, int nf, unsigned long long mask, int lane)
+	__device__ __forceinline__ void rows_load_any(float* __restrict__ tile, const float* __restrict__ src, const uint32_t* list, int nrows,
+	                                              int g0, size_t row_floats, int first_float, int nf, int lane)
 	{
-		int g = lane / nf, pos = lane - g * nf;
-		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
-		for (int e = lane; e < SHB_GPW * nf; e += WAVE)
+		int r = lane / nf, pos = lane - r * nf;
+		const int dr = WAVE / nf, dpos = WAVE - dr * nf;
+		for (int e = lane; e < nrows * nf; e += WAVE)
 		{
-			if (g0 + g < P && ((mask >> g) & 1ull)) tile[g * SHB_STRIDE + pos] = src[(size_t)(g0 + g) * row_floats + first_float + pos];
-			g += dg; pos += dpos;
-			if (pos >= nf) { pos -= nf; g++; }
+			tile[r * SHB_STRIDE + pos] = src[(size_t)(g0 + list[r]) * row_floats + first_float + pos];
+			r += dr; pos += dpos;
+			if (pos >= nf) { pos -= nf; r++; }
 		}
 	}
-	__device__ __forceinline__ void tile_store_any(const float* __restrict__ tile, float* __restrict__ dst, int g0, int P, size_t row_floats,
-	                                               int first_float, int nf, unsigned long long mask, int lane, bool accum)
+	__device__ __forceinline__ void rows_store_any(const float* __restrict__ tile, float* __restrict__ dst, const uint32_t* list, int nrows,
+	                                               int g0, size_t row_floats, int first_float, int nf, int lane, bool accum)
 	{
-		int g = lane / nf, pos = lane - g * nf;
-		const int dg = WAVE / nf, dpos = WAVE - dg * nf;
-		for (int e = lane; e < SHB_GPW * nf; e += WAVE)
+		int r = lane / nf, pos = lane - r * nf;
+		const int dr = WAVE / nf, dpos = WAVE - dr * nf;
+		for (int e = lane; e < nrows * nf; e += WAVE)
 		{
-			if (g0 + g < P)
-			{
-				float* d = dst + (size_t)(g0 + g) * row_floats + first_float + pos;
-				const bool live = (mask >> g) & 1ull;
-				if (!accum) *d = live ? tile[g * SHB_STRIDE + pos] : 0.f;
-				else if (live) *d += tile[g * SHB_STRIDE + pos];
-			}
-			g += dg; pos += dpos;
-			if (pos >= nf) { pos -= nf; g++; }
+			float* d = dst + (size_t)(g0 + list[r]) * row_floats + first_float + pos;
+			if (accum) *d += tile[r * SHB_STRIDE + pos];
+			else *d = tile[r * SHB_STRIDE + pos];
+			r += dr; pos += dpos;
+			if (pos >= nf) { pos -= nf; r++; }
 		}
+	}
+
+	// dL_dRGB of a Gaussian as the blend backward left it, clamped channels zeroed (backward.cu:158-161)
+	__device__ __forceinline__ float3 colour_gradient(const ShBwdArgs& a, int idx)
+	{
+		const float4 w = *reinterpret_cast<const float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS);
+		float3 dRGB = make_float3(w.x, w.y, w.z);
+		const uint8_t cl = a.clamped[idx];
+		if (cl & 1) dRGB.x = 0.f;
+		if (cl & 2) dRGB.y = 0.f;
+		if (cl & 4) dRGB.z = 0.f;
+		return dRGB;
 	}
 
 	// One wave per workgroup: the tile is wave-private, so no workgroup barrier is needed anywhere (LDS
@@ -170,122 +182,161 @@ namespace fdgs
 	template <bool STAGE>
 	__global__ void __launch_bounds__(WAVE) sh_bwd_kernel(const ShBwdArgs a)
 	{
-		__shared__ float tile[SHB_GPW * SHB_STRIDE];
+		__shared__ float tile[SHB_ROWS * SHB_STRIDE];
+		__shared__ uint32_t s_list[SHB_SPAN];     // span-local indices of the live Gaussians, ascending
 		const int lane = threadIdx.x;
-		float* row = tile + (lane < SHB_GPW ? lane : 0) * SHB_STRIDE;
-		const int g0 = blockIdx.x * SHB_GPW;
-		const int tid_g = g0 + lane;
-		const bool valid = lane < SHB_GPW && tid_g < a.P;
-		const int idx = valid ? tid_g : a.P - 1;
-		const bool visible = valid && a.radii[idx] > 0; // backward.cu:873
+		const int g0 = blockIdx.x * SHB_SPAN;
 		const size_t row_floats = (size_t)3 * a.M;
-
 		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
 		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
 		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+		const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-		// per-Gaussian prologue
-		const float3 campos = make_float3(a.campos[0], a.campos[1], a.campos[2]);
-		const float3 mean = make_float3(a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
-		const float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z); // Q4: shifted mean
-		const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-		const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-		float3 dRGB = make_float3(a.gacc[(size_t)idx * GRAD_ACC_WORDS + 0], a.gacc[(size_t)idx * GRAD_ACC_WORDS + 1], a.gacc[(size_t)idx * GRAD_ACC_WORDS + 2]);
-		const uint8_t cl = a.clamped[idx];
-		if (cl & 1) dRGB.x = 0.f;   // clamped channels get no gradient (backward.cu:158-161)
-		if (cl & 2) dRGB.y = 0.f;
-		if (cl & 4) dRGB.z = 0.f;
-		// Every output of this kernel is linear in dRGB.  A Gaussian that is visible but contributed to no pixel
-		// (occluded, or too faint everywhere: 58 % of the visible ones on the C3 workload) has dRGB == 0 exactly:
-		// its coefficients are not read and its gradient row is zero (not touched at all when accumulating).
-		const bool live = visible && (dRGB.x != 0.f || dRGB.y != 0.f || dRGB.z != 0.f);
-		const unsigned long long vmask = __ballot(live);
-		const float dir_t = sh3d ? 0.f : a.ts[idx] - a.timestamp;
-		float l[16], dX[16], dY[16], dZ[16];
-		sh_tables(a.D, dir.x, dir.y, dir.z, !sh3d, l, dX, dY, dZ);
-
-		float3 gx = make_float3(0.f, 0.f, 0.f), gy = gx, gz = gx, gt = gx;
-		float tk_stage[2] = { 0.f, 0.f };   // cos factors of the two time blocks (deferred mode hands them to the flush)
-		for (int blk = 0; blk < nblocks; blk++)
-		{
-			const int nk = (blk == 0) ? ncoef0 : 16;
-			const int first_float = 48 * blk;
-			const bool vec = a.vec_ok && nk == 16;
-			if (vec) tile_load16(tile, a.shs, g0, a.P, row_floats, first_float, vmask, lane);
-			else tile_load_any(tile, a.shs, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane);
-			__builtin_amdgcn_wave_barrier();
-			if (live)
-			{
-				float tk = 1.f, dtk_dt = 0.f;
-				if (blk == 1)
-				{
-					tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
-					dtk_dt = (float)(sin(2 * REF_PI * dir_t / a.time_duration) * 2 * REF_PI / a.time_duration); // Q2
-				}
-				else if (blk == 2)
-				{
-					tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
-					dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
-				}
-				if (a.analytic) dtk_dt = -dtk_dt;   // d cos(u) / dt = -sin(u) du/dt
-				if (blk == 1) tk_stage[0] = tk;
-				if (blk == 2) tk_stage[1] = tk;
-				float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
+		// ---- which Gaussians of the span carry a colour gradient (visible: backward.cu:873) ----
+		unsigned long long live_mask[SHB_SPAN / WAVE];
+		int n = 0;
 #pragma unroll
-				for (int k = 0; k < 16; k++)   // fully unrolled: the tables stay in registers (no dynamic indexing)
-				{
-					if (k >= nk) break;
-					const float3 s = s_ld3(row, k);
-					float basis = l[k];
-					if (blk == 0 && k == 1 && !sh3d && !a.analytic) basis = l[0]; // Q1
-					if (!STAGE)
-					{
-						const float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
-						row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
-					}
-					st = s_add(st, s_scl(l[k], s));
-					sx = s_add(sx, s_scl(dX[k], s));
-					sy = s_add(sy, s_scl(dY[k], s));
-					sz = s_add(sz, s_scl(dZ[k], s));
-				}
-				if (blk == 0) { gx = sx; gy = sy; gz = sz; }
-				else
-				{
-					gx = s_add(gx, s_scl(tk, sx)); gy = s_add(gy, s_scl(tk, sy)); gz = s_add(gz, s_scl(tk, sz));
-					gt = a.analytic ? s_add(gt, s_scl(dtk_dt, st)) : s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
-				}
-			}
-			__builtin_amdgcn_wave_barrier();
-			if (!STAGE)
-			{
-				if (vec) tile_store16(tile, a.dL_dsh, g0, a.P, row_floats, first_float, vmask, lane, a.accum != 0);
-				else tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, first_float, 3 * nk, vmask, lane, a.accum != 0);
-				__builtin_amdgcn_wave_barrier();
-			}
-		}
-		if (STAGE)
+		for (int h = 0; h < SHB_SPAN / WAVE; h++)
 		{
-			// what the flush needs to rebuild this view's contribution basis(dir) x time factor x dRGB to dL_dsh
-			if (valid)
+			const int idx = g0 + h * WAVE + lane;
+			const bool valid = idx < a.P;
+			bool live = false;
+			if (valid && a.radii[idx] > 0)
 			{
-				a.stage[2 * (size_t)idx] = live ? make_float4(dRGB.x, dRGB.y, dRGB.z, tk_stage[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
-				a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, tk_stage[1]);
+				const float3 dRGB = colour_gradient(a, idx);
+				live = dRGB.x != 0.f || dRGB.y != 0.f || dRGB.z != 0.f;
 			}
+			live_mask[h] = __ballot(live);
+			if (live) s_list[n + __popcll(live_mask[h] & lt_mask)] = (uint32_t)(h * WAVE + lane);
+			n += __popcll(live_mask[h]);
+			// a Gaussian without a colour gradient: all of its outputs are zero.  Record words 12..15 already are (the record is
+			// all zero when the blend backward starts and nobody else writes them); dL_dsh: below; the flush looks at dRGB only
+			if (STAGE && valid && !live) a.stage[2 * (size_t)idx] = make_float4(0.f, 0.f, 0.f, 0.f);
 		}
-		// coefficients above the active degree get a zero gradient (nothing to add when accumulating)
-		else if (!a.accum)
+		__builtin_amdgcn_wave_barrier();
+
+		if (!STAGE && !a.accum)
 		{
+			// dL_dsh is fully written by this call: zero rows for the Gaussians without a colour gradient, zeros beyond the
+			// active degrees for the others (nothing to add when accumulating)
 			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
-			const int rest = (int)row_floats - written;
-			if (rest > 0) tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written, rest > 48 ? 48 : rest, 0ull, lane, false);
-			for (int done = 48; done < rest; done += 48)
-				tile_store_any(tile, a.dL_dsh, g0, a.P, row_floats, written + done, min(48, rest - done), 0ull, lane, false);
+			const int span = min(SHB_SPAN, a.P - g0);
+			if (a.vec_ok && (written & 3) == 0)
+			{
+				const int RC = (int)row_floats / 4, total = span * RC;
+				const int dg = WAVE / RC, dq = WAVE - dg * RC;
+				int g = lane / RC, q = lane - g * RC;
+				for (int c = lane; c < total; c += WAVE)
+				{
+					const bool live = (live_mask[g >> 6] >> (g & 63)) & 1ull;
+					if (!live || 4 * q >= written)
+						*reinterpret_cast<float4*>(a.dL_dsh + (size_t)(g0 + g) * row_floats + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+					g += dg; q += dq;
+					if (q >= RC) { q -= RC; g++; }
+				}
+			}
+			else
+			{
+				const int rf = (int)row_floats, total = span * rf;
+				const int dg = WAVE / rf, dpos = WAVE - dg * rf;
+				int g = lane / rf, pos = lane - g * rf;
+				for (int e = lane; e < total; e += WAVE)
+				{
+					const bool live = (live_mask[g >> 6] >> (g & 63)) & 1ull;
+					if (!live || pos >= written) a.dL_dsh[(size_t)(g0 + g) * row_floats + pos] = 0.f;
+					g += dg; pos += dpos;
+					if (pos >= rf) { pos -= rf; g++; }
+				}
+			}
 		}
-		if (valid)
+
+		// ---- the live Gaussians, one per lane ----
+		const float3 campos = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+		for (int r0 = 0; r0 < n; r0 += SHB_ROWS)
 		{
-			float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+			const int nrows = min(SHB_ROWS, n - r0);
+			const uint32_t* list = s_list + r0;
+			const bool live = lane < nrows;
+			const int idx = g0 + (int)list[live ? lane : 0];
+			float* row = tile + lane * SHB_STRIDE;
+			// per-Gaussian prologue
+			const float3 mean = make_float3(a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
+			const float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z); // Q4: shifted mean
+			const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+			const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+			const float3 dRGB = colour_gradient(a, idx);
+			const float dir_t = sh3d ? 0.f : a.ts[idx] - a.timestamp;
+			float l[16], dX[16], dY[16], dZ[16];
+			sh_tables(a.D, dir.x, dir.y, dir.z, !sh3d, l, dX, dY, dZ);
+
+			float3 gx = make_float3(0.f, 0.f, 0.f), gy = gx, gz = gx, gt = gx;
+			float tk_stage[2] = { 0.f, 0.f };   // cos factors of the two time blocks (deferred mode hands them to the flush)
+			for (int blk = 0; blk < nblocks; blk++)
+			{
+				const int nk = (blk == 0) ? ncoef0 : 16;
+				const int first_float = 48 * blk;
+				const bool vec = a.vec_ok && nk == 16;
+				if (vec) rows_load16(tile, a.shs, list, nrows, g0, row_floats, first_float, lane);
+				else rows_load_any(tile, a.shs, list, nrows, g0, row_floats, first_float, 3 * nk, lane);
+				__builtin_amdgcn_wave_barrier();
+				if (live)
+				{
+					float tk = 1.f, dtk_dt = 0.f;
+					if (blk == 1)
+					{
+						tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
+						dtk_dt = (float)(sin(2 * REF_PI * dir_t / a.time_duration) * 2 * REF_PI / a.time_duration); // Q2
+					}
+					else if (blk == 2)
+					{
+						tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+						dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
+					}
+					if (a.analytic) dtk_dt = -dtk_dt;   // d cos(u) / dt = -sin(u) du/dt
+					if (blk == 1) tk_stage[0] = tk;
+					if (blk == 2) tk_stage[1] = tk;
+					float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
+#pragma unroll
+					for (int k = 0; k < 16; k++)   // fully unrolled: the tables stay in registers (no dynamic indexing)
+					{
+						if (k >= nk) break;
+						const float3 s = s_ld3(row, k);
+						float basis = l[k];
+						if (blk == 0 && k == 1 && !sh3d && !a.analytic) basis = l[0]; // Q1
+						if (!STAGE)
+						{
+							const float3 d = s_scl(blk == 0 ? basis : tk * basis, dRGB);
+							row[3 * k] = d.x; row[3 * k + 1] = d.y; row[3 * k + 2] = d.z;
+						}
+						st = s_add(st, s_scl(l[k], s));
+						sx = s_add(sx, s_scl(dX[k], s));
+						sy = s_add(sy, s_scl(dY[k], s));
+						sz = s_add(sz, s_scl(dZ[k], s));
+					}
+					if (blk == 0) { gx = sx; gy = sy; gz = sz; }
+					else
+					{
+						gx = s_add(gx, s_scl(tk, sx)); gy = s_add(gy, s_scl(tk, sy)); gz = s_add(gz, s_scl(tk, sz));
+						gt = a.analytic ? s_add(gt, s_scl(dtk_dt, st)) : s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (!STAGE)
+				{
+					if (vec) rows_store16(tile, a.dL_dsh, list, nrows, g0, row_floats, first_float, lane, a.accum != 0);
+					else rows_store_any(tile, a.dL_dsh, list, nrows, g0, row_floats, first_float, 3 * nk, lane, a.accum != 0);
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
 			if (live)
 			{
+				if (STAGE)
+				{
+					// what the flush needs to rebuild this view's contribution basis(dir) x time factor x dRGB to dL_dsh
+					a.stage[2 * (size_t)idx] = make_float4(dRGB.x, dRGB.y, dRGB.z, tk_stage[0]);
+					a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, tk_stage[1]);
+				}
+				float4 o;
 				const float3 ddir = make_float3(s_dot(gx, dRGB), s_dot(gy, dRGB), s_dot(gz, dRGB));
 				// dnormvdv, auxiliary.h:108-118
 				const float3 v = dir_orig;
@@ -295,8 +346,8 @@ namespace fdgs
 				o.y = (-v.x * v.y * ddir.x + (sum2 - v.y * v.y) * ddir.y - v.z * v.y * ddir.z) * invsum32;
 				o.z = (-v.x * v.z * ddir.x - v.y * v.z * ddir.y + (sum2 - v.z * v.z) * ddir.z) * invsum32;
 				o.w = sh3d ? 0.f : s_dot(gt, dRGB);
+				reinterpret_cast<float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS)[3] = o;
 			}
-			reinterpret_cast<float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS)[3] = o;
 		}
 	}
 
@@ -314,8 +365,8 @@ namespace fdgs
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
 		a.stage = reinterpret_cast<float4*>(out.sh_stage);
-		if (out.sh_stage) hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(div_up(s.P, SHB_GPW)), dim3(WAVE), 0, stream, a);
-		else hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(div_up(s.P, SHB_GPW)), dim3(WAVE), 0, stream, a);
+		if (out.sh_stage) hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(div_up(s.P, SHB_SPAN)), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(div_up(s.P, SHB_SPAN)), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
 	}
 
