@@ -189,70 +189,118 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 
 	uint32_t* counters = (uint32_t*)(img + IL.tile_counters);
 	uint32_t* ctl = (uint32_t*)(img + IL.bin_ctl);
-	int R = 0, longest = 0;
-	uint32_t* point_list = nullptr;
-	if (P > 0)
+	const float* records = (const float*)(geom + GL.records);
+	if (P == 0)
 	{
-		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, stream), "preprocess_fwd");
-		const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
-		STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
-		// num_rendered (and the longest tile list) come back through a pinned, device-mapped mailbox that the scan kernel
-		// writes itself: {R, longest, ticket}.  The host spins on the ticket -- the forward's one wait for the device, as
-		// rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the ticket does not show up
-		// (a failed launch), the stream is synchronised and the error reported.
-		struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t ticket = 0; };
-		static thread_local Mailbox box;
-		if (!box.host)
-		{
-			void* h = nullptr;
-			HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped), "hipHostMalloc");
-			memset(h, 0, 64);
-			void* d = nullptr;
-			HIP_TRY(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
-			box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
-		}
-		const uint32_t ticket = ++box.ticket ? box.ticket : ++box.ticket;   // never 0
-		STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev, ticket, stream), "tile scan");
-		{
-			bool arrived = false;
-			for (long spin = 0; spin < 400000000L && !arrived; spin++)   // bounded: seconds
-			{
-				arrived = __atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) == ticket;
-				// now and then: has the stream drained (or failed) without the ticket showing up?  then stop spinning
-				if (!arrived && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(stream) != hipErrorNotReady) break;
-			}
-			if (!arrived)
-			{
-				HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
-				if (__atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) != ticket) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
-			}
-		}
-		R = (int)box.host[0];
-		longest = (int)box.host[1];
-		if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
-	}
-	*num_rendered = R;
-
-	const bool big = longest > tile_sort_lds_cap();
-	const BinLayout BL = bin_layout(R, big);
-	char* bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
-	if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
-
-	if (R > 0)
-	{
-		point_list = (uint32_t*)(bin + BL.point_list);
-		uint32_t* pairs = (uint32_t*)(bin + BL.pairs);
-		STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter((const uint16_t*)(geom + GL.rect), (const float*)(geom + GL.depths), P, gx, T,
-		                          counters, pairs, stream), "tile scatter");
-		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, longest, pairs, point_list, ranges, big ? (void*)(bin + BL.big_scratch) : nullptr,
-		                       stream), "tile sort");
-	}
-	else
+		// nothing to bin; the blend kernel still writes background colour / T = 1 everywhere
+		if (!alloc(alloc_user, FDGS_BUF_BINNING, bin_layout(0, false).total)) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
 		STAGE(FDGS_STAGE_TILE_SORT, hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, nullptr, ranges, final_T, n_contrib, stream), "blend_fwd");
+		return FDGS_OK;
+	}
 
-	// with nothing to blend the kernel still writes background colour / T = 1 everywhere
-	STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, (const float*)(geom + GL.records), point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
-	return FDGS_OK;
+	STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, stream), "preprocess_fwd");
+	const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
+	const float* depths = (const float*)(geom + GL.depths);
+	STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
+	// num_rendered (and the longest tile list) come back through a pinned, device-mapped mailbox that the scan kernel
+	// writes itself: {R, longest, ticket}.  The host spins on the ticket -- the forward's one wait for the device, as
+	// rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the ticket does not show up
+	// (a failed launch), the stream is synchronised and the error reported.
+	struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t ticket = 0; };
+	static thread_local Mailbox box;
+	if (!box.host)
+	{
+		void* h = nullptr;
+		HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped), "hipHostMalloc");
+		memset(h, 0, 64);
+		void* d = nullptr;
+		HIP_TRY(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
+		box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
+	}
+	const uint32_t ticket = ++box.ticket ? box.ticket : ++box.ticket;   // never 0
+	STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev, ticket, stream), "tile scan");
+
+	// Run-ahead.  The reference stops here until num_rendered has come back and sizes the binning buffers with it
+	// (rasterizer_impl.cu:302-306): the device idles for a host round trip in the middle of the forward.  Views follow each
+	// other with similar sizes, so the rest of the forward is enqueued right away with buffers sized by this thread's
+	// previous call plus headroom; scatter and sort compare num_rendered with that capacity ON THE DEVICE and leave
+	// everything alone when it does not fit (the sort then reports every tile empty, so the blend behind it reads nothing).
+	// The host picks up the mailbox afterwards (written long before) and, when the guess was too small, starts over from
+	// the scatter pass with exact sizes.
+	struct RunAhead { long long capacity = 0; int longest = 0; };
+	static thread_local RunAhead guess;
+	const int lds_cap = tile_sort_lds_cap();
+	const bool ahead = guess.capacity > 0 && !debug;
+	const long long ahead_cap = guess.capacity;
+	const int ahead_longest = guess.longest;
+	char* bin = nullptr;
+	BinLayout BL = bin_layout(0, false);
+	bool has_scratch = false;   // BL includes the global sort scratch
+	const auto enqueue_rest = [&](long long capacity, int sort_longest, bool scatter) -> int
+	{
+		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
+		uint32_t* pairs = (uint32_t*)(bin + BL.pairs);
+		if (scatter)
+			STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)capacity, stream), "tile scatter");
+		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, sort_longest, pairs, point_list, ranges,
+		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, stream), "tile sort");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
+		return FDGS_OK;
+	};
+	if (ahead)
+	{
+		has_scratch = ahead_longest > lds_cap;
+		BL = bin_layout((int)ahead_cap, has_scratch);
+		bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
+		if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+		if ((rc = enqueue_rest(ahead_cap, ahead_longest, true)) != FDGS_OK) return rc;
+	}
+
+	{
+		bool arrived = false;
+		for (long spin = 0; spin < 400000000L && !arrived; spin++)   // bounded: seconds
+		{
+			arrived = __atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) == ticket;
+			// now and then: has the stream drained (or failed) without the ticket showing up?  then stop spinning
+			if (!arrived && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(stream) != hipErrorNotReady) break;
+		}
+		if (!arrived)
+		{
+			HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
+			if (__atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) != ticket) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
+		}
+	}
+	const int R = (int)box.host[0], longest = (int)box.host[1];
+	if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
+	*num_rendered = R;
+	guess.capacity = std::min<long long>((long long)R + R / 4 + 4096, 0x7fffffffLL);
+	guess.longest = longest + longest / 4;
+
+	if (ahead && R <= ahead_cap && longest <= ahead_longest) return FDGS_OK;    // the usual case: everything is already on its way
+	if (ahead && R <= ahead_cap)
+	{
+		// the lists were scattered, but some are longer than the sort instances that were launched take (they were left
+		// unsorted): sort again with the right instances.  Lists beyond the LDS need 8 bytes per instance of scratch; if the
+		// buffer was sized without it, the scratch is borrowed from the stream-ordered allocator for this one call.
+		void* extra = nullptr;
+		if (longest > lds_cap && !has_scratch)
+		{
+			HIP_TRY(hipMallocAsync(&extra, (size_t)ahead_cap * 8 + 256, stream), "hipMallocAsync (sort scratch)");
+		}
+		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
+		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, longest, (const uint32_t*)(bin + BL.pairs), point_list, ranges,
+		                       extra ? extra : (has_scratch ? (void*)(bin + BL.big_scratch) : nullptr), ctl, (uint32_t)ahead_cap, stream), "tile sort");
+		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
+		return FDGS_OK;
+	}
+	// first call of this thread, debug mode, or more instances than guessed (nothing was scattered): exact sizes
+	has_scratch = longest > lds_cap;
+	BL = bin_layout(R, has_scratch);
+	bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
+	if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+	return enqueue_rest(R, longest, true);
 }
 
 extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,

@@ -109,9 +109,12 @@ namespace fdgs
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream);
 	// host_box (optional): device pointer of a pinned host mailbox {R, longest, ticket} the kernel writes directly
 	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, hipStream_t stream);
-	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs, hipStream_t stream);
+	// scatter / sort may be launched before the host knows num_rendered: they compare ctl[0] with `capacity` (the instances
+	// pairs / point_list hold) and leave everything alone -- the sort reports every tile empty -- when it does not fit
+	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
+	                               const uint32_t* ctl, uint32_t capacity, hipStream_t stream);
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
-	                            void* big_scratch, hipStream_t stream);
+	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, hipStream_t stream);
 	int tile_sort_lds_cap();                                   // lists longer than this need the global scratch
 	void tile_sort_debug_limits(int lds_cap, int rank_max);    // test hook (fdgs_debug_tile_sort_limits); <= 0 restores the default
 

@@ -88,9 +88,12 @@ namespace fdgs
 	template <bool SCATTER>
 	__global__ void __launch_bounds__(BIN_T) tile_bin_lds_kernel(const ushort4* __restrict__ rect, const float* __restrict__ depths, int P,
 	                                                             int grid_x, int T, int rounds /* batch = rounds * BIN_T Gaussians per workgroup */,
-	                                                             uint32_t* __restrict__ counters, uint2* __restrict__ pairs)
+	                                                             uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
+	                                                             const uint32_t* __restrict__ ctl, uint32_t capacity)
 	{
 		extern __shared__ uint32_t s_hist[];   // T words
+		// launched before the host knew num_rendered (capi.hip): `pairs` holds `capacity` instances -- more than that: leave everything alone
+		if (SCATTER && ctl[0] > capacity) return;
 		const int lane = threadIdx.x & 63;
 		for (int t = threadIdx.x; t < T; t += BIN_T) s_hist[t] = 0u;
 		__syncthreads();
@@ -152,8 +155,10 @@ namespace fdgs
 	// Images with more tiles than an LDS histogram holds: the same walk with one global atomic per instance.
 	template <bool SCATTER>
 	__global__ void __launch_bounds__(256) tile_bin_direct_kernel(const ushort4* __restrict__ rect, const float* __restrict__ depths, int P,
-	                                                              int grid_x, uint32_t* __restrict__ counters, uint2* __restrict__ pairs)
+	                                                              int grid_x, uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
+	                                                              const uint32_t* __restrict__ ctl, uint32_t capacity)
 	{
+		if (SCATTER && ctl[0] > capacity) return;
 		const int g = blockIdx.x * blockDim.x + threadIdx.x;
 		ushort4 r = make_ushort4(0, 0, 0, 0);
 		uint32_t key = 0u;
@@ -302,8 +307,16 @@ namespace fdgs
 	__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
 	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
 	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
-	                                                           int lds_cap, int rank_max)
+	                                                           int lds_cap, int rank_max, const uint32_t* __restrict__ ctl, uint32_t capacity,
+	                                                           int last /* no further instance takes what this one leaves */)
 	{
+		// launched before the host knew num_rendered: if the buffers are too small the scatter pass did not run either (the counters
+		// are not list ends) -- every tile is reported empty, so that whatever is queued behind reads nothing, and the host starts over
+		if (ctl[0] > capacity)
+		{
+			if (n_lo == 0 && threadIdx.x == 0) ranges[blockIdx.x] = make_uint2(0u, 0u);
+			return;
+		}
 		// LDS: lds_cap + TS_PAD depth keys, then lds_cap ids, in bucket order (8 lds_cap + 4 TS_PAD bytes); the same
 		// bytes hold the 64-bit keys of the bitonic fall-back and, at the end, the ids in final order
 		extern __shared__ uint32_t s_dyn[];
@@ -328,7 +341,14 @@ namespace fdgs
 		}
 		if (n > lds_cap)
 		{
-			if (big_scratch == nullptr) return;   // left to the next instance
+			if (big_scratch == nullptr)
+			{
+				// left to the next instance.  If there is none -- a run-ahead launch sized by the previous view (capi.hip), which the
+				// host repeats with the right instances -- the ids go out unsorted, so that the blend queued behind reads valid ones
+				if (last)
+					for (int i = tid; i < n; i += THREADS) point_list[start + i] = pairs[start + i].y;
+				return;
+			}
 			// a list longer than the LDS takes: bitonic sort in global scratch (slot s of the list = slot start + s)
 			volatile u64* S = big_scratch + start;
 			for (int i = tid; i < n; i += THREADS)
@@ -513,7 +533,7 @@ namespace fdgs
 
 	template <bool SCATTER>
 	static hipError_t launch_tile_bin(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                                  hipStream_t stream)
+	                                  const uint32_t* ctl, uint32_t capacity, hipStream_t stream)
 	{
 		if (P <= 0) return hipSuccess;
 		const ushort4* r4 = reinterpret_cast<const ushort4*>(rect);
@@ -525,16 +545,17 @@ namespace fdgs
 			if (attr != hipSuccess) return attr;
 			const int rounds = bin_rounds(T);
 			hipLaunchKernelGGL(tile_bin_lds_kernel<SCATTER>, dim3(div_up(P, rounds * BIN_T)), dim3(BIN_T), (size_t)T * 4, stream, r4, depths, P,
-			                   grid_x, T, rounds, counters, p2);
+			                   grid_x, T, rounds, counters, p2, ctl, capacity);
 		}
 		else
-			hipLaunchKernelGGL(tile_bin_direct_kernel<SCATTER>, dim3(div_up(P, 256)), dim3(256), 0, stream, r4, depths, P, grid_x, counters, p2);
+			hipLaunchKernelGGL(tile_bin_direct_kernel<SCATTER>, dim3(div_up(P, 256)), dim3(256), 0, stream, r4, depths, P, grid_x, counters, p2,
+			                   ctl, capacity);
 		return hipGetLastError();
 	}
 
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream)
 	{
-		return launch_tile_bin<false>(rect, nullptr, P, grid_x, T, counters, nullptr, stream);
+		return launch_tile_bin<false>(rect, nullptr, P, grid_x, T, counters, nullptr, nullptr, 0u, stream);
 	}
 
 	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, hipStream_t stream)
@@ -545,9 +566,9 @@ namespace fdgs
 	}
 
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                               hipStream_t stream)
+	                               const uint32_t* ctl, uint32_t capacity, hipStream_t stream)
 	{
-		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, stream);
+		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, ctl, capacity, stream);
 	}
 
 	// test hook: cap the list length the LDS instances take, and the crowded-bucket threshold
@@ -561,14 +582,14 @@ namespace fdgs
 
 	template <int THREADS>
 	static void launch_sort_instance(const uint32_t* counters, int T, const uint2* pairs, uint32_t* point_list, uint2* ranges, u64* big,
-	                                 int n_lo, int cap, int rank_max, hipStream_t stream)
+	                                 int n_lo, int cap, int rank_max, const uint32_t* ctl, uint32_t capacity, bool last, hipStream_t stream)
 	{
 		hipLaunchKernelGGL((tile_sort_kernel<THREADS>), dim3(T), dim3(THREADS), (size_t)cap * 8 + TS_PAD * 4, stream, counters, pairs, point_list,
-		                   ranges, big, n_lo, cap, rank_max);
+		                   ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0);
 	}
 
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
-	                            void* big_scratch, hipStream_t stream)
+	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, hipStream_t stream)
 	{
 		const int lds_cap = g_lds_cap.load(), rank_max = g_rank_max.load();
 		const uint2* p2 = reinterpret_cast<const uint2*>(pairs);
@@ -585,12 +606,12 @@ namespace fdgs
 		const auto lds_keys = [&](int c) { return min(c, max(64, div_up(longest_lds, 64) * 64)); };
 		const bool overflow = max_count > lds_cap;   // somebody has to take the global path
 		if (max_count <= c1 || c2 == c1)
-			launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, stream);
+			launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, stream);
 		else
 		{
 			const bool second = max_count > c2 && c3 > c2;
-			launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, stream);
-			if (second) launch_sort_instance<512>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c2, lds_keys(c3), rank_max, stream);
+			launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, stream);
+			if (second) launch_sort_instance<512>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c2, lds_keys(c3), rank_max, ctl, capacity, true, stream);
 		}
 		return hipGetLastError();
 	}

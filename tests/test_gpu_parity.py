@@ -323,6 +323,33 @@ def test_tile_sort_long_lists(gpu_device):
     assert (seen > 4096).any() and ((seen > 2048) & (seen <= 4096)).any() and ((seen > 1024) & (seen <= 2048)).any()
 
 
+def test_forward_run_ahead_matches_exact_path(gpu_device):
+    """The forward enqueues scatter / sort / blend before the host knows num_rendered, with buffers sized by the thread's
+    previous call (capi.hip "run-ahead"); debug mode takes the exact path (wait, then size).  A sequence of scenes that
+    makes every guess wrong in turn -- more instances than the capacity, longer lists than the sort instances launched, lists
+    that need the global scratch the buffer was sized without, then much smaller again -- must give bit-identical results
+    either way (the forward is deterministic: no float atomics)."""
+    seq = [SC("a", 3000, 160, 128, 0, 0, 0.02, 1.0, True, 4, True),      # small
+           SC("b", 30000, 320, 240, 0, 0, 0.03, 1.0, True, 4, True),     # 10 x the instances: over capacity
+           SC("c", 30000, 128, 96, 0, 0, 0.03, 1.0, True, 4, True),      # fewer instances, longer lists: other sort instances
+           SC("d", 40000, 96, 64, 0, 0, 0.03, 1.0, True, 4, True),       # lists beyond 4096: global scratch the buffer was sized without
+           SC("e", 2000, 208, 160, 0, 0, 0.01, 1.0, True, 4, True),      # tiny
+           SC("f", 20000, 320, 240, 1, 0, 0.03, 1.0, True, 4, True),     # back up
+           SC("g", 20000, 320, 240, 1, 0, 0.03, 1.0, True, 4, True)]     # same sizes again: the guess fits
+    longest = []
+    for k, cfg in enumerate(seq):
+        scene = synth.make_scene(cfg, seed=40 + k)
+        fast, _ = run_hip(scene, gpu_device, None)
+        exact, _ = run_hip(dict(scene, debug=True), gpu_device, None)
+        label = "run-ahead step %s" % cfg.name
+        assert fast["R"] == exact["R"], label
+        for key in ("point_list", "ranges", "n_contrib", "final_T", "out_color", "out_depth", "out_flow", "radii"):
+            np.testing.assert_array_equal(fast[key], exact[key], err_msg="%s %s" % (label, key))
+        longest.append(int((exact["ranges"][:, 1].astype(np.int64) - exact["ranges"][:, 0]).max()))
+    print("run-ahead sequence: R-longest per step", longest)
+    assert longest[3] > 4096 > longest[2] + longest[2] // 4 and longest[1] > 2 * longest[0] and longest[4] < longest[3] // 8
+
+
 def test_binning_many_tiles_direct_path(gpu_device):
     """More tiles than an LDS histogram holds (> 36 864): count / scatter fall back to one global atomic per instance."""
     scene = synth.make_scene(SC("v", 3000, 3104, 3104, 0, 0, 0.02, 1.0, True, 4, True), seed=14)

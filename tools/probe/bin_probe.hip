@@ -93,17 +93,17 @@ int main(int argc, char** argv)
 					CK(hipEventRecord(ev[0]));
 					CK(hipMemsetAsync(d_cnt, 0, (T + 4) * 4));
 					CK(hipEventRecord(ev[1]));
-					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<false>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, (const float*)nullptr, P, gx, T, rounds, d_cnt, (uint2*)nullptr);
-					else hipLaunchKernelGGL(tile_bin_direct_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, (const float*)nullptr, P, gx, d_cnt, (uint2*)nullptr);
+					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<false>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, (const float*)nullptr, P, gx, T, rounds, d_cnt, (uint2*)nullptr, (const uint32_t*)nullptr, 0u);
+					else hipLaunchKernelGGL(tile_bin_direct_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, (const float*)nullptr, P, gx, d_cnt, (uint2*)nullptr, (const uint32_t*)nullptr, 0u);
 					CK(hipEventRecord(ev[2]));
 					hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, 0, d_cnt, T, per_thread, d_ctl, (uint32_t*)nullptr, 0u);
 					CK(hipEventRecord(ev[3]));
 					CK(hipMemcpy(ctl, d_ctl, 8, hipMemcpyDeviceToHost));
 					CK(hipEventRecord(ev[6]));
-					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<true>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, d_depth, P, gx, T, rounds, d_cnt, d_pairs);
-					else hipLaunchKernelGGL(tile_bin_direct_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, d_depth, P, gx, d_cnt, d_pairs);
+					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<true>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, d_depth, P, gx, T, rounds, d_cnt, d_pairs, (const uint32_t*)d_ctl, 0xFFFFFFFFu);
+					else hipLaunchKernelGGL(tile_bin_direct_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, d_depth, P, gx, d_cnt, d_pairs, (const uint32_t*)d_ctl, 0xFFFFFFFFu);
 					CK(hipEventRecord(ev[4]));
-					CK(launch_tile_sort(d_cnt, T, (int)ctl[1], (const uint32_t*)d_pairs, d_pl, (uint32_t*)d_ranges, d_big, 0));
+					CK(launch_tile_sort(d_cnt, T, (int)ctl[1], (const uint32_t*)d_pairs, d_pl, (uint32_t*)d_ranges, d_big, (const uint32_t*)d_ctl, 0xFFFFFFFFu, 0));
 					CK(hipEventRecord(ev[5]));
 					CK(hipDeviceSynchronize());
 					CK(hipGetLastError());
