@@ -7,6 +7,8 @@
 #define REP16(X) X(0,8) X(1,9) X(2,10) X(3,11) X(4,12) X(5,13) X(6,14) X(7,15) X(0,8) X(1,9) X(2,10) X(3,11) X(4,12) X(5,13) X(6,14) X(7,15)
 template <int KIND> __global__ void __launch_bounds__(256) k(float* out)
 {
+	__shared__ float4 s_lds[1024];   // 16 KB
+	if (threadIdx.x == 0 && out == nullptr) s_lds[0] = make_float4(0, 0, 0, 0);
 	float r[16];
 	for (int i = 0; i < 16; i++) r[i] = threadIdx.x * 0.5f + i;
 	const int addr = ((threadIdx.x ^ 16) & 63) * 4;
@@ -22,6 +24,22 @@ template <int KIND> __global__ void __launch_bounds__(256) k(float* out)
 		if (KIND == 2) { REP16(SW32) }
 		if (KIND == 3) { REP16(SW16) }
 		if (KIND == 4) { REP16(BPERM) asm volatile("s_waitcnt lgkmcnt(0)"); }
+		if (KIND == 5 || KIND == 6)
+		{
+			// 16 ds_read_b128: KIND 5 every lane the same address (the blend kernels' queue reads), KIND 6 lane-private addresses
+			float4 q[4];
+			const int base = (KIND == 5 ? 0 : (int)(threadIdx.x & 63) * 16) + (it & 7) * 1024;
+#pragma unroll
+			for (int rep = 0; rep < 4; rep++)
+			{
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[i]) : "v"(base), "n"(i * 2048));
+				asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+				for (int i = 0; i < 4; i++) r[i] += q[i].x + q[i].y + q[i].z + q[i].w;
+			}
+		}
 	}
 	float s = 0;
 	for (int i = 0; i < 16; i++) s += r[i];
@@ -44,5 +62,6 @@ int main()
 	float* out; hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
 	run<0>("v_add_f32", out); run<1>("v_add_f32_dpp", out); run<2>("v_permlane32_swap", out); run<3>("v_permlane16_swap", out);
 	run<4>("ds_bpermute_b32", out);
+	run<5>("ds_read_b128 same addr", out); run<6>("ds_read_b128 per lane", out);
 	return 0;
 }
