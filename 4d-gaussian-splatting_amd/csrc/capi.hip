@@ -162,6 +162,14 @@ extern "C" void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max) {
 extern "C" const char* fdgs_last_error(void) { return g_err; }
 extern "C" int fdgs_version(void) { return FDGS_VERSION; }
 
+// how the forward calls of this process went: [0] everything enqueued ahead of num_rendered and kept, [1] ahead but sorted
+// again (longer lists than guessed), [2] exact sizes (first call of a thread, debug mode, or more instances than guessed)
+static std::atomic<long long> g_run_ahead[3];
+extern "C" void fdgs_debug_run_ahead_stats(int64_t* counts3)
+{
+	for (int k = 0; k < 3; k++) counts3[k] = (int64_t)g_run_ahead[k].load();
+}
+
 extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                                       fdgs_alloc_fn alloc, void* alloc_user, void* stream_v, int32_t* num_rendered)
 {
@@ -277,9 +285,10 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	guess.capacity = std::min<long long>((long long)R + R / 4 + 4096, 0x7fffffffLL);
 	guess.longest = longest + longest / 4;
 
-	if (ahead && R <= ahead_cap && longest <= ahead_longest) return FDGS_OK;    // the usual case: everything is already on its way
+	if (ahead && R <= ahead_cap && longest <= ahead_longest) { g_run_ahead[0]++; return FDGS_OK; }   // the usual case: everything is already on its way
 	if (ahead && R <= ahead_cap)
 	{
+		g_run_ahead[1]++;
 		// the lists were scattered, but some are longer than the sort instances that were launched take (they were left
 		// unsorted): sort again with the right instances.  Lists beyond the LDS need 8 bytes per instance of scratch; if the
 		// buffer was sized without it, the scratch is borrowed from the stream-ordered allocator for this one call.
@@ -296,6 +305,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		return FDGS_OK;
 	}
 	// first call of this thread, debug mode, or more instances than guessed (nothing was scattered): exact sizes
+	g_run_ahead[2]++;
 	has_scratch = longest > lds_cap;
 	BL = bin_layout(R, has_scratch);
 	bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);

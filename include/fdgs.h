@@ -183,6 +183,11 @@ int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                            fdgs_alloc_fn alloc, void* alloc_user, void* stream,
                            int32_t* num_rendered);
 
+/* Introspection for tests: how the forward calls of this process went -- counts3[0] scatter / sort / blend enqueued before
+ * num_rendered was back and kept, [1] enqueued ahead but sorted again (longer tile lists than the previous call suggested),
+ * [2] sized exactly after the wait (first call of a thread, debug mode, more instances than the previous call suggested). */
+void fdgs_debug_run_ahead_stats(int64_t* counts3);
+
 /* Backward pass: blend backward -> fused cov2D / projection / SH / covariance backward. */
 int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backward_in* in,
                             const fdgs_backward_out* out, void* stream);
