@@ -336,17 +336,21 @@ def test_forward_run_ahead_matches_exact_path(gpu_device):
            SC("e", 2000, 208, 160, 0, 0, 0.01, 1.0, True, 4, True),      # tiny
            SC("f", 20000, 320, 240, 1, 0, 0.03, 1.0, True, 4, True),     # back up
            SC("g", 20000, 320, 240, 1, 0, 0.03, 1.0, True, 4, True)]     # same sizes again: the guess fits
-    longest = []
+    from fdgs import _capi
+    longest, paths = [], []
     for k, cfg in enumerate(seq):
         scene = synth.make_scene(cfg, seed=40 + k)
+        before = _capi.run_ahead_stats()
         fast, _ = run_hip(scene, gpu_device, None)
+        paths.append(tuple(b - a for a, b in zip(before, _capi.run_ahead_stats())))
         exact, _ = run_hip(dict(scene, debug=True), gpu_device, None)
         label = "run-ahead step %s" % cfg.name
         assert fast["R"] == exact["R"], label
         for key in ("point_list", "ranges", "n_contrib", "final_T", "out_color", "out_depth", "out_flow", "radii"):
             np.testing.assert_array_equal(fast[key], exact[key], err_msg="%s %s" % (label, key))
         longest.append(int((exact["ranges"][:, 1].astype(np.int64) - exact["ranges"][:, 0]).max()))
-    print("run-ahead sequence: R-longest per step", longest)
+    print("run-ahead sequence: longest list per step", longest, "path (kept, sorted again, exact) per step", paths)
+    assert paths[1] == (0, 0, 1) and paths[3] == (0, 1, 0) and paths[4] == (1, 0, 0) and paths[6] == (1, 0, 0), paths
     assert longest[3] > 4096 > longest[2] + longest[2] // 4 and longest[1] > 2 * longest[0] and longest[4] < longest[3] // 8
 
 
