@@ -27,7 +27,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
                  fuse_sh_adam: bool = True):
-        """``fuse_sh_adam``: on one rank with B > 1 views per step, the SH coefficients are updated straight from the views'
+        """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
         bucket is what the all-reduce sums)."""
@@ -66,8 +66,9 @@ class StepPipeline:
                 self._gacc = torch.zeros((m.P, 16), dtype=torch.float32, device=self.dev)
         # deferred SH gradient: with B > 1 views per step every view stages the 7 numbers it contributes to dL_dsh and ONE
         # flush per step writes the 3 M floats per Gaussian (instead of a read-modify-write of them per view)
-        defer_sh = B > 1
-        fuse = defer_sh and self.fuse_sh_adam and self.world == 1
+        # (on one rank also for B = 1: the stage then feeds the fused SH flush + Adam kernel and dL_dsh is never written at all)
+        fuse = self.fuse_sh_adam and self.world == 1
+        defer_sh = B > 1 or fuse
         if defer_sh and (self._sh_stage is None or self._sh_stage.shape[0] != B or self._sh_stage.shape[1] != m.P):
             with torch.cuda.stream(self.sB):
                 self._sh_stage = torch.empty((B, m.P, 8), dtype=torch.float32, device=self.dev)
