@@ -52,15 +52,17 @@ namespace fdgs
 		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		for (int i = tid; i < SHH * SW; i += STHREADS)
+		// halo element i = tid, tid + 256, ...  ->  (row, column), carried along instead of divided out every trip
+		for (int i = tid, ly = tid / SW, lx = tid - (tid / SW) * SW; i < SHH * SW; i += STHREADS)
 		{
-			const int ly = i / SW, lx = i - ly * SW;
 			const int gy = y0 + ly - SR, gx = x0 + lx - SR;
-			const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+			const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
 			const size_t o = plane + (size_t)gy * W + gx;
 			v2f p = { 0.0f, 0.0f };                    // zero padding (F.conv2d padding = 5)
 			if (in) { p.x = img1[o]; p.y = img2[o]; }
 			s_in[ly][lx] = p;
+			ly += STHREADS / SW; lx += STHREADS % SW;
+			if (lx >= SW) { lx -= SW; ly++; }
 		}
 		__syncthreads();
 
@@ -115,10 +117,12 @@ namespace fdgs
 				const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
 				const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
 				const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sg1 + sg2 + C2;
-				const float inv = 1.0f / (Cc * D);
+				// 1 / Cc and 1 / D by v_rcp_f32 (1 ulp): three IEEE divisions were a seventh of the kernel's instructions
+				const float rC = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D);
+				const float inv = rC * rD;
 				const float m = A * B * inv;
 				// total derivative w.r.t. mu1 (through A, B, Cc, D), and w.r.t. the raw moments E[x^2], E[xy]
-				const float dm_dA = B * inv, dm_dB = A * inv, dm_dC = -m / Cc, dm_dD = -m / D;
+				const float dm_dA = B * inv, dm_dB = A * inv, dm_dC = -m * rC, dm_dD = -m * rD;
 				const size_t o = plane + (size_t)gy * W + gx;
 				dm_dmu1[o] = dm_dA * 2.f * mu2 - dm_dB * 2.f * mu2 + dm_dC * 2.f * mu1 - dm_dD * 2.f * mu1;
 				dm_de11[o] = dm_dD;
@@ -156,16 +160,17 @@ namespace fdgs
 		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		for (int i = tid; i < SHH * SW; i += STHREADS)
+		for (int i = tid, ly = tid / SW, lx = tid - (tid / SW) * SW; i < SHH * SW; i += STHREADS)
 		{
-			const int ly = i / SW, lx = i - ly * SW;
 			const int gy = y0 + ly - SR, gx = x0 + lx - SR;
-			const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+			const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
 			const size_t o = plane + (size_t)gy * W + gx;
 			v2f p = { 0.0f, 0.0f };
 			float q = 0.0f;
 			if (in) { p.x = dm_dmu1[o]; p.y = dm_de11[o]; q = dm_de12[o]; }
 			s_p[ly][lx] = p; s_q[ly][lx] = q;
+			ly += STHREADS / SW; lx += STHREADS % SW;
+			if (lx >= SW) { lx -= SW; ly++; }
 		}
 		__syncthreads();
 		if (tid < SHH * (STX / 4))
