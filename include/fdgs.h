@@ -61,7 +61,10 @@ extern "C" {
 /* Resize callback: must return a DEVICE pointer to at least `bytes` bytes,
  * 256-byte aligned, valid until the matching backward has finished.
  * Mirrors std::function<char*(size_t)> in CudaRasterizer::Rasterizer::forward
- * (rasterizer.h:28-31). */
+ * (rasterizer.h:28-31).  Like the reference's resize lambdas it may be called more than once for the same buffer
+ * within one forward call (FDGS_BUF_BINNING: the forward sizes it from the previous call before num_rendered is known and
+ * asks again if that was too small); the latest answer is the buffer, an earlier one may be released in stream order
+ * (work already enqueued on `stream` may still touch it). */
 typedef void* (*fdgs_alloc_fn)(void* user, int which, size_t bytes);
 
 /* Everything that describes one view; shared by forward and backward
@@ -176,8 +179,10 @@ typedef struct fdgs_backward_out
 	                             gradients (88 % of the bytes at M = 48) while the geometry backward still runs. */
 } fdgs_backward_out;
 
-/* Forward pass: preprocess -> tile count -> tile scan -> [R read back] -> tile scatter -> per-tile
- * local sort (+ ranges) -> per-tile blend: 6 kernel launches.  *num_rendered receives R.
+/* Forward pass: preprocess -> tile count -> tile scan -> tile scatter -> per-tile local sort (+ ranges) -> per-tile
+ * blend: 6 kernel launches, all enqueued before the host waits for num_rendered (the scan kernel writes it into a pinned
+ * mailbox; scatter / sort check on the device that the binning buffer, sized from the calling thread's previous forward, is
+ * large enough, and the call starts over from the scatter pass if not).  *num_rendered receives R when the call returns.
  * `stream` is a hipStream_t passed as void* so that this header needs no HIP include. */
 int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                            fdgs_alloc_fn alloc, void* alloc_user, void* stream,
