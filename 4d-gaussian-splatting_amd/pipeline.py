@@ -74,6 +74,7 @@ class StepPipeline:
                 self._sh_stage = torch.empty((B, m.P, 8), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
         sh_handle = []
+        sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
         for b in range(B):
             with torch.cuda.stream(self.sF):
                 rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
@@ -88,7 +89,17 @@ class StepPipeline:
                 # last view of the step on several ranks: the SH gradients (88 % of the bucket) are final once this view's
                 # SH backward has run -- their all-reduce starts there and travels while the geometry backward runs
                 after_sh = None
-                if b == B - 1 and ((defer_sh and not fuse) or self.world > 1):
+                if b == B - 1 and fuse and self.sB is not self.sF:
+                    # the SH stages are complete once this view's SH backward has run: the fused SH flush + Adam (HBM-bound)
+                    # goes onto the idle F stream and runs next to the geometry backward (latency-bound) of stream B
+                    def after_sh():
+                        done = torch.cuda.Event()
+                        done.record(self.sB)
+                        with torch.cuda.stream(self.sF):
+                            self.sF.wait_event(done)
+                            self.opt.step_count += 1
+                            sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
+                elif b == B - 1 and ((defer_sh and not fuse) or self.world > 1):
                     def after_sh():
                         if defer_sh:
                             _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
@@ -108,8 +119,10 @@ class StepPipeline:
         with torch.cuda.stream(self.sB):
             # the losses were scaled by 1 / (B * world): SUM = mean; Adam on chunk k overlaps the all-reduce of chunk k+1
             if fuse:
-                self.opt.step_count += 1
-                if self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()):
+                if not sh_stepped:
+                    self.opt.step_count += 1
+                    sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
+                if sh_stepped[0]:
                     self.opt.step_range(0, m.offsets["_features"][0])
                 else:   # layout the fused kernel does not take: the two passes
                     _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
