@@ -7,7 +7,7 @@
 //   * every output of the kernel is linear in the Gaussian's dL_dRGB, and a Gaussian that is visible but contributed to no
 //     pixel (occluded, or too faint everywhere: 58 % of the visible ones on C3) has dL_dRGB == 0 exactly.  A wave first
 //     scans a span of 128 consecutive Gaussians and ballot-compacts the LIVE ones (those with a colour gradient) into a list;
-//     the others only get their zeros (accumulator words 12..15, the stage record / the dL_dsh row);
+//     the others only get their zeros (the stage record / the dL_dsh row; their accumulator words 12..15 are zero already);
 //   * the live Gaussians are then taken 64 at a time, one per lane: their rows are staged block by block (16 coefficients
 //     = 192 B per Gaussian) through a wave-private LDS tile with coalesced dwordx4 loads (gathered rows, contiguous runs);
 //   * each lane walks ITS Gaussian's row in LDS (row stride 49 floats: conflict free), accumulates the

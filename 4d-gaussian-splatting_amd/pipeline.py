@@ -64,7 +64,7 @@ class StepPipeline:
         if self._gacc is None or self._gacc.shape[0] != m.P:
             with torch.cuda.stream(self.sB):
                 self._gacc = torch.zeros((m.P, 16), dtype=torch.float32, device=self.dev)
-        # deferred SH gradient: with B > 1 views per step every view stages the 7 numbers it contributes to dL_dsh and ONE
+        # deferred SH gradient: with B > 1 views per step every view stages the 8 numbers it contributes to dL_dsh and ONE
         # flush per step writes the 3 M floats per Gaussian (instead of a read-modify-write of them per view)
         # (on one rank also for B = 1: the stage then feeds the fused SH flush + Adam kernel and dL_dsh is never written at all)
         fuse = self.fuse_sh_adam and self.world == 1
