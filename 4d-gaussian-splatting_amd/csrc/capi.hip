@@ -298,9 +298,14 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 			HIP_TRY(hipMallocAsync(&extra, (size_t)ahead_cap * 8 + 256, stream), "hipMallocAsync (sort scratch)");
 		}
 		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
-		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, longest, (const uint32_t*)(bin + BL.pairs), point_list, ranges,
-		                       extra ? extra : (has_scratch ? (void*)(bin + BL.big_scratch) : nullptr), ctl, (uint32_t)ahead_cap, stream), "tile sort");
-		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");
+		hipError_t sorted;
+		{
+			StageTimer timer__(FDGS_STAGE_TILE_SORT, stream);
+			sorted = launch_tile_sort(counters, T, longest, (const uint32_t*)(bin + BL.pairs), point_list, ranges,
+			                          extra ? extra : (has_scratch ? (void*)(bin + BL.big_scratch) : nullptr), ctl, (uint32_t)ahead_cap, stream);
+		}
+		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");   // stream-ordered: after the sort, whether it was launched or not
+		HIP_TRY(sorted, "tile sort");
 		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
 	}
