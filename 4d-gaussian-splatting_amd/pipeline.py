@@ -21,18 +21,22 @@ from . import _capi
 from .fused import raw_backward, raw_forward, raw_settings
 from .gaussian_renderer import diff_gaussian_rasterization as _dgr
 from .loss import l1_ssim_grad, l1_ssim_loss
-from .train_host import allreduce_and_step, allreduce_sh_begin
+from .train_host import allreduce_and_step, allreduce_sh_begin, gather_sh_stages_begin
 
 
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
-                 fuse_sh_adam: bool = True):
+                 fuse_sh_adam: bool = True, gather_max_views: int = 16):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
         bucket is what the all-reduce sums)."""
         self.model, self.opt, self.world, self.lam = model, optimizer, int(world_size), float(lambda_dssim)
         self.fuse_sh_adam = bool(fuse_sh_adam)
+        # several ranks, up to this many views per step over all ranks: the ranks exchange the views' SH stages (32 B per
+        # Gaussian and view, all-gather) instead of all-reducing the dense SH gradient (12 M B per Gaussian), and every rank
+        # runs the fused update on all of them (train_host.gather_sh_stages_begin); beyond it the dense all-reduce is cheaper
+        self.gather_max_views = int(gather_max_views)
         dev = model.flat.device
         self.dev = dev
         # (Tried and dropped, with measurements on MI355X: a high-priority F stream and a CU-masked B stream change
@@ -68,12 +72,14 @@ class StepPipeline:
         # flush per step writes the 3 M floats per Gaussian (instead of a read-modify-write of them per view)
         # (on one rank also for B = 1: the stage then feeds the fused SH flush + Adam kernel and dL_dsh is never written at all)
         fuse = self.fuse_sh_adam and self.world == 1
-        defer_sh = B > 1 or fuse
+        gather = self.fuse_sh_adam and self.world > 1 and self.world * B <= self.gather_max_views
+        defer_sh = B > 1 or fuse or gather
         if defer_sh and (self._sh_stage is None or self._sh_stage.shape[0] != B or self._sh_stage.shape[1] != m.P):
             with torch.cuda.stream(self.sB):
                 self._sh_stage = torch.empty((B, m.P, 8), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
         sh_handle = []
+        sh_gather = []     # gather: (work, stages of all ranks)
         sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
         for b in range(B):
             with torch.cuda.stream(self.sF):
@@ -99,6 +105,9 @@ class StepPipeline:
                             self.sF.wait_event(done)
                             self.opt.step_count += 1
                             sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
+                elif b == B - 1 and gather:
+                    def after_sh():   # the stages of this rank are complete: their exchange travels while the geometry backward runs
+                        sh_gather.append(gather_sh_stages_begin(self._sh_stage, self.world))
                 elif b == B - 1 and ((defer_sh and not fuse) or self.world > 1):
                     def after_sh():
                         if defer_sh:
@@ -128,6 +137,19 @@ class StepPipeline:
                     _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
                                    rs.force_sh_3d, _dgr.analytic_sh_gradients())
                     self.opt.step_range(0, m.flat.numel())
+            elif gather:
+                import torch.distributed as dist
+                feat = m.offsets["_features"][0]
+                geo = dist.all_reduce(m.flat_grad[:feat], op=dist.ReduceOp.SUM, async_op=True)   # 17 floats per Gaussian
+                work, stages = sh_gather[0]
+                self.opt.step_count += 1
+                work.wait()
+                ok = self.opt.step_sh_staged(stages, rs, _dgr.analytic_sh_gradients())
+                if not ok:   # layout the fused kernel does not take: every rank builds the same summed dL_dsh from all the stages
+                    _capi.sh_flush(stages, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim, rs.force_sh_3d,
+                                   _dgr.analytic_sh_gradients())
+                geo.wait()
+                self.opt.step_range(0, feat if ok else m.flat.numel())
             else:
                 allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None)
         main.wait_stream(self.sB)

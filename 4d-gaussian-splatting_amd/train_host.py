@@ -293,6 +293,28 @@ def allreduce_sh_begin(model: GaussianParams, world_size: int, chunks: int = 3):
     return [(dist.all_reduce(model.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi) for lo, hi in bounds]
 
 
+def gather_sh_stages_begin(stages: torch.Tensor, world_size: int):
+    """Starts the exchange of the ranks' staged SH gradients ([B, P, 8] each, fdgs_backward_out.sh_stage) and returns
+    (work, gathered): after ``work.wait()`` ``gathered`` is [world * B, P, 8], rank-major, bit-identical on every rank.
+
+    With few views per step this replaces the all-reduce of the dense SH gradient: a view contributes 32 bytes per Gaussian to
+    the exchange instead of the 12 M bytes per Gaussian of dL_dsh (world * B = 8 views at M = 48: 77 MB gathered per rank
+    against 2 * 7/8 * 173 MB moved by a ring all-reduce), and every rank then feeds the same stages, in the same order, to the
+    fused SH flush + Adam kernel (FlatAdam.step_sh_staged) -- the replicas stay bit-identical.
+    RCCL: one all-gather.  Other backends (the gloo debug / test runs): the same result as an all-reduce of a buffer that is
+    zero outside the rank's own slice."""
+    import torch.distributed as dist
+    B = stages.shape[0]
+    shape = (world_size * B,) + tuple(stages.shape[1:])
+    if dist.get_backend() == "nccl":
+        gathered = torch.empty(shape, dtype=stages.dtype, device=stages.device)
+        return dist.all_gather_into_tensor(gathered, stages.contiguous(), async_op=True), gathered
+    gathered = torch.zeros(shape, dtype=stages.dtype, device=stages.device)
+    r = dist.get_rank()
+    gathered[r * B:(r + 1) * B].copy_(stages)
+    return dist.all_reduce(gathered, op=dist.ReduceOp.SUM, async_op=True), gathered
+
+
 def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: int, chunks: int = 4, average: bool = False,
                        sh_handle=None) -> None:
     """Gradient all-reduce + Adam with the two overlapped: the bucket is cut into pieces, all all-reduces are issued

@@ -77,6 +77,9 @@ def parse_args():
                     help="fused kernels driven through autograd (render_raw + fused_l1_ssim + backward()) on one stream, "
                          "instead of the explicit two-stream step pipeline (fdgs/pipeline.py)")
     ap.add_argument("--no-overlap", action="store_true", help="step pipeline on a single stream (A/B for the overlap)")
+    ap.add_argument("--dense-sh-exchange", action="store_true",
+                    help="N > 1: always all-reduce the dense SH gradient (default: up to 16 views per step over all ranks exchange "
+                         "the views' 32-byte SH stages by all-gather instead, train_host.gather_sh_stages_begin)")
     return ap.parse_args()
 
 
@@ -205,7 +208,8 @@ def main():
     use_pipeline = not (args.reference_host or args.autograd or args.torch_loss or args.no_loss)
     if use_pipeline:
         from fdgs.pipeline import StepPipeline
-        steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap)
+        steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
+                                gather_max_views=0 if args.dense_sh_exchange else 16)
 
     def step():
         if use_pipeline:
@@ -236,7 +240,8 @@ def main():
     # Untimed stage pass on ONE stream (kernel time, not queueing time behind the other stream's launches): every
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.
     if use_pipeline:
-        stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False)
+        stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
+                                  gather_max_views=0 if args.dense_sh_exchange else 16)
         stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)  # noqa: E731
     else:
         stage_step = step
@@ -315,6 +320,16 @@ def main():
         torch.cuda.synchronize(dev)
         dt_fwd = max_over_ranks(time.perf_counter() - t1, world, dev)
 
+    # frame-parallel replicas must hold bit-identical parameters after the timed steps (every rank applied the same update)
+    replicas_identical = None
+    if world > 1:
+        import torch.distributed as dist
+        digest = torch.stack([model.flat.double().sum(), model.flat.double().abs().sum()])
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+
     if rank != 0:
         return
     P, M, W, H = model.P, model.M, scene["W"], scene["H"]
@@ -358,7 +373,7 @@ def main():
         "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4),
         "ms_per_image": round(dt / (args.steps * B) * 1e3, 4),
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,

@@ -86,6 +86,14 @@ def _worker(rank, world, port, q):
         flats = [torch.zeros_like(model.flat) for _ in range(world)]
         dist.all_gather(flats, model.flat.detach())
         assert torch.equal(flats[0], flats[1]), "replicas diverged"
+    # the exchange of staged SH gradients (few views per step: all-gather of 32 B per Gaussian and view instead of the dense
+    # all-reduce): every rank ends up with everybody's stages, rank-major, bit-identical
+    B, P = 3, 257
+    mine = torch.randn(B, P, 8, generator=torch.Generator().manual_seed(500 + rank))
+    work, stages = train_host.gather_sh_stages_begin(mine, world)
+    work.wait()
+    want = torch.cat([torch.randn(B, P, 8, generator=torch.Generator().manual_seed(500 + r)) for r in range(world)])
+    assert stages.shape == (world * B, P, 8) and torch.equal(stages, want)
     q.put((rank, float(model.flat.detach().abs().sum())))
     dist.destroy_process_group()
 

@@ -1,7 +1,8 @@
 """GPU: the multi-rank control flow of bench.py on ONE GPU (FDGS_BENCH_DEBUG_SHARE_GPU: both ranks on cuda:0, gloo
 collectives) -- what the driver launches on 2/4/8 GPUs over RCCL, minus the fabric: torch.distributed.run, the barrier /
-max-over-ranks timing, the early all-reduce of the SH gradients (split backward), chunked all-reduce + Adam, one JSON line
-from rank 0.  Both modes: 4 views per rank and step (weak scaling) and 1 view per rank and step (BASELINE configs[3])."""
+max-over-ranks timing, the exchange of the SH gradient (all-gather of the views' stages + fused update; or, forced with
+--dense-sh-exchange, the early all-reduce of the dense gradient with the split backward and chunked all-reduce + Adam), one JSON
+line from rank 0, replicas bit-identical.  Both modes: 4 views per rank and step (weak scaling) and 1 view per rank and step (BASELINE configs[3])."""
 import json
 import os
 import socket
@@ -22,12 +23,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("views", [4, 1])
-def test_bench_two_ranks_share_one_gpu(views, gpu_device):
+@pytest.mark.parametrize("views,dense", [(4, False), (1, False), (4, True)])
+def test_bench_two_ranks_share_one_gpu(views, dense, gpu_device):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-           "--workload", "C2", "--views-per-step", str(views), "--cpu-samples", "0"]
+           "--workload", "C2", "--views-per-step", str(views), "--cpu-samples", "0"] + (["--dense-sh-exchange"] if dense else [])
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -36,3 +37,4 @@ def test_bench_two_ranks_share_one_gpu(views, gpu_device):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["views_per_step_per_gpu"] == views and d["config"]["global_batch"] == 2 * views
     assert "roofline" in d and d["roofline"]["frac"] > 0
+    assert d["replicas_identical"] is True   # both ranks hold bit-identical parameters after the steps
