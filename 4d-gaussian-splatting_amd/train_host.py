@@ -306,7 +306,7 @@ def gather_sh_stages_begin(stages: torch.Tensor, world_size: int):
     import torch.distributed as dist
     B = stages.shape[0]
     shape = (world_size * B,) + tuple(stages.shape[1:])
-    if dist.get_backend() == "nccl":
+    if dist.get_backend() == "nccl" and hasattr(dist, "all_gather_into_tensor"):
         gathered = torch.empty(shape, dtype=stages.dtype, device=stages.device)
         return dist.all_gather_into_tensor(gathered, stages.contiguous(), async_op=True), gathered
     gathered = torch.zeros(shape, dtype=stages.dtype, device=stages.device)
