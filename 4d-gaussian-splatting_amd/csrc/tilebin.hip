@@ -251,8 +251,9 @@ namespace fdgs
 	// Two instances: one WAVE per tile for lists of up to 1024 entries (no workgroup barriers at all), 256 threads per
 	// tile for up to 4096; longer lists are sorted by a bitonic network in global scratch.
 	constexpr int TS_NS = 64;                   // splitters
-	constexpr int TS_G = 4;                     // keys a thread handles side by side (independent LDS chains in flight)
-	constexpr int TS_ITEMS = 8;                 // keys per thread (two groups of TS_G)
+	constexpr int TS_G = 2;                     // keys a thread handles side by side (independent LDS chains in flight); 4 wastes half of
+	                                            // the lanes on the typical 470-entry list of a 256-thread instance, 1 serialises the chains
+	constexpr int TS_ITEMS = 8;                 // keys per thread (four groups of TS_G)
 	constexpr int TS_LARGE = 512 * TS_ITEMS;    // 4096: the longest list sorted in LDS (128 / 256 / 512 threads per tile by length)
 	constexpr int TS_DIRECT = 96;               // lists this short skip the bucketing
 	typedef unsigned long long u64;
