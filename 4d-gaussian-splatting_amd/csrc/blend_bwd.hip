@@ -120,13 +120,16 @@ namespace fdgs
 		return g[0];
 	}
 
+	// slot_off: this lane's word of the record, in bytes.  The address is the uniform base plus a 32-bit byte offset
+	// (a record is 64 bytes: P < 2^26, checked by the launcher), which the atomic takes as SGPR base + VGPR offset -- one
+	// shift-add per entry instead of 64-bit pointer arithmetic.
 	template <bool AUX>
-	__device__ __forceinline__ void reduce_and_add(float (&g)[12], float* slot_ptr, bool slot_writer, uint32_t eid)
+	__device__ __forceinline__ void reduce_and_add(float (&g)[12], float* gacc, uint32_t slot_off, bool slot_writer, uint32_t eid)
 	{
 		float total = AUX ? row_transpose_reduce12(g) : row_transpose_reduce9(g);
 		total += __shfl_xor(total, 16);       // across the four 16-lane rows
 		total += __shfl_xor(total, 32);
-		if (slot_writer) atomicAdd(slot_ptr + (size_t)eid * GRAD_ACC_WORDS, total);
+		if (slot_writer) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gacc) + (eid * (uint32_t)(GRAD_ACC_WORDS * 4) + slot_off)), total);
 	}
 
 	// AUX = false: only the colour image carries an upstream gradient (dL_dout_depth / _alpha / _flow are NULL = zero),
@@ -187,7 +190,7 @@ namespace fdgs
 		// accumulator record: colour r,g,b 0-2, depth 3, flow 4-5, then the moments of q = G dL/dalpha: q dx, q dy 6-7,
 		// q dx^2, q dy^2 8-9, q dx dy 10, q 11 (preprocess_bwd turns them into dL/dmean2D, dL/dconic, dL/dopacity).  One record = one 64-B segment, so the 12-lane atomic instruction is ONE memory-side
 		// request instead of five (the reference scatters into five arrays, backward.cu:1116-1133).
-		float* const slot_ptr = gacc + (lane & 15);
+		const uint32_t slot_off = (uint32_t)(lane & 15) * 4u;
 		const bool slot_writer = lane < NG && (AUX || lane < 3 || lane > 5);
 
 		float S = 0.f, Lc = 0.f, last_alpha = 0.f;
@@ -239,7 +242,7 @@ namespace fdgs
 			g[9] = qy * dy;
 			g[10] = qx * dy;
 			g[11] = q;
-			reduce_and_add<AUX>(g, slot_ptr, slot_writer, eid);
+			reduce_and_add<AUX>(g, gacc, slot_off, slot_writer, eid);
 		};
 
 		// Both entries of a pair have contributing pixels (the common case): the same arithmetic as `entry` twice, but
@@ -277,8 +280,8 @@ namespace fdgs
 			}
 			ga[6] = qx.x; ga[7] = qy.x; ga[8] = qxx.x; ga[9] = qyy.x; ga[10] = qxy.x; ga[11] = q.x;
 			gb[6] = qx.y; gb[7] = qy.y; gb[8] = qxx.y; gb[9] = qyy.y; gb[10] = qxy.y; gb[11] = q.y;
-			reduce_and_add<AUX>(ga, slot_ptr, slot_writer, eid0);
-			reduce_and_add<AUX>(gb, slot_ptr, slot_writer, eid1);
+			reduce_and_add<AUX>(ga, gacc, slot_off, slot_writer, eid0);
+			reduce_and_add<AUX>(gb, gacc, slot_off, slot_writer, eid1);
 		};
 
 		for (int top = wave_last; top > 0; top -= WAVE)
@@ -291,8 +294,8 @@ namespace fdgs
 			if (pos >= 0)
 			{
 				id = point_list[range.x + (uint32_t)pos];
-				a = records[3 * (size_t)id + 0];
-				b = records[3 * (size_t)id + 1];
+				a = record_word(records, id, 0);
+				b = record_word(records, id, 1);
 				keep = block_reaches(a, b, rx0, rx1, ry0, ry1);
 			}
 			const unsigned long long mask = __ballot(keep);
@@ -300,7 +303,7 @@ namespace fdgs
 			if (keep)
 			{
 				const int slot = __popcll(mask & lt_mask); // back-to-front order is preserved
-				const float4 c = records[3 * (size_t)id + 2];
+				const float4 c = record_word(records, id, 2);
 				const int pr = slot >> 1, h = slot & 1;
 				float* q0 = reinterpret_cast<float*>(&s_q[0][pr]) + h;
 				float* q1 = reinterpret_cast<float*>(&s_q[1][pr]) + h;
@@ -364,6 +367,7 @@ namespace fdgs
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records), \
 		                   s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib, \
 		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow, out.grad_accum)
+		if (s.P >= (1 << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets into the 64-byte accumulator records
 		if (in.dL_dout_depth || in.dL_dout_alpha || in.dL_dout_flow) LAUNCH_BWD(true);
 		else LAUNCH_BWD(false);
 #undef LAUNCH_BWD

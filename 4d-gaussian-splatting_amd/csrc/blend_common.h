@@ -42,6 +42,13 @@ namespace fdgs
 		return r;
 	}
 
+	// float4 k of Gaussian id's 48-byte blend record: uniform base + 32-bit byte offset (P < 2^26, checked by the launchers), so
+	// that the gather needs one multiply-add per lane instead of 64-bit pointer arithmetic
+	__device__ __forceinline__ float4 record_word(const float4* __restrict__ records, uint32_t id, uint32_t k)
+	{
+		return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(records) + (id * 48u + 16u * k));
+	}
+
 	struct BlockId { int tile, sub; };
 	// Workgroup id -> (tile, 8x8 sub-block).  Workgroups are dealt round-robin to the 8 XCDs
 	// (id % 8); give each XCD a contiguous band of tiles and keep the 4 sub-blocks of a tile on

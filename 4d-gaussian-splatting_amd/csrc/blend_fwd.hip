@@ -63,8 +63,8 @@ namespace fdgs
 			if (pos < n)
 			{
 				id = point_list[range.x + pos];
-				a = records[3 * (size_t)id + 0];
-				b = records[3 * (size_t)id + 1];
+				a = record_word(records, id, 0);
+				b = record_word(records, id, 1);
 				keep = block_reaches(a, b, rx0, rx1, ry0, ry1);
 			}
 			const unsigned long long mask = __ballot(keep);
@@ -72,7 +72,7 @@ namespace fdgs
 			if (keep)
 			{
 				const int slot = __popcll(mask & lt_mask);
-				const float4 c = records[3 * (size_t)id + 2];
+				const float4 c = record_word(records, id, 2);
 				const int pr = slot >> 1, h = slot & 1;
 				float* q0 = reinterpret_cast<float*>(&s_q[0][pr]) + h;
 				float* q1 = reinterpret_cast<float*>(&s_q[1][pr]) + h;
@@ -159,6 +159,7 @@ namespace fdgs
 	{
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
 		const int ntiles = gx * gy;
+		if (s.P >= (1 << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets into the 48-byte records
 		hipLaunchKernelGGL(blend_fwd_kernel, dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream,
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records),
 		                   s.W, s.H, gx, ntiles, s.bg,
