@@ -149,9 +149,9 @@ namespace fdgs
 		// word, as in blend_fwd.hip: (x0,x1,y0,y1) (A0,A1,B0,B1) (C0,C1,o0,o1) (r0,r1,g0,g1) (b0,b1,d0,d1) (fx0,fx1,fy0,fy1):
 		// the arithmetic up to alpha runs as packed fp32 on two entries per instruction.
 		constexpr int QP = WAVE / 2 + 1;
-		__shared__ float4 s_q[6][QP];
-		__shared__ uint2 s_pp[QP];   // list positions of the two entries
-		__shared__ uint2 s_ii[QP];   // their Gaussian ids
+		// row 6: (list position of entry 0, of entry 1, Gaussian id of entry 0, of entry 1) -- same stride as the other rows, so the
+		// loop addresses the whole queue with ONE base register and immediate offsets
+		__shared__ float4 s_q[7][QP];
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -313,8 +313,8 @@ namespace fdgs
 				float* q5 = reinterpret_cast<float*>(&s_q[5][pr]) + h;
 				q0[0] = a.x; q0[2] = a.y; q1[0] = a.z; q1[2] = a.w; q2[0] = b.x; q2[2] = b.y;
 				q3[0] = b.z; q3[2] = b.w; q4[0] = c.x; q4[2] = c.y; q5[0] = c.z; q5[2] = c.w;
-				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[h] = (uint32_t)pos;
-				(reinterpret_cast<uint32_t*>(&s_ii[pr]))[h] = id;
+				uint32_t* e = reinterpret_cast<uint32_t*>(&s_q[6][pr]) + h;
+				e[0] = (uint32_t)pos; e[2] = id;
 			}
 			if (lane == 0 && (cnt & 1))
 			{
@@ -322,8 +322,8 @@ namespace fdgs
 				const int pr = cnt >> 1;
 #pragma unroll
 				for (int k = 0; k < 6; k++) { float* q = reinterpret_cast<float*>(&s_q[k][pr]) + 1; q[0] = 0.f; q[2] = 0.f; }
-				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[1] = 0x7fffffffu;
-				(reinterpret_cast<uint32_t*>(&s_ii[pr]))[1] = 0u;
+				uint32_t* e = reinterpret_cast<uint32_t*>(&s_q[6][pr]) + 1;
+				e[0] = 0x7fffffffu; e[2] = 0u;
 			}
 			__syncthreads();
 
@@ -331,7 +331,8 @@ namespace fdgs
 			for (int i = 0; i < npairs; i++)
 			{
 				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i], Q5 = s_q[5][i];
-				const uint2 pp = s_pp[i], ii = s_ii[i];
+				const uint4 pi = *reinterpret_cast<const uint4*>(&s_q[6][i]);
+				const uint2 pp = make_uint2(pi.x, pi.y), ii = make_uint2(pi.z, pi.w);
 				// packed head for both entries, with the reference's association per element (forward.cu:585,
 				// backward.cu:1036): keeps alpha -- and with it the alpha >= 1/255 decision -- within an ulp of the oracle's
 				// (a cheaper factored form flipped cliff pairs and was dropped)

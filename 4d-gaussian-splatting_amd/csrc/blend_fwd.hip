@@ -29,8 +29,9 @@ namespace fdgs
 		// (fx0,fx1,fy0,fy1).  One b128 read then delivers the same quantity of both entries in an aligned register
 		// pair, so the per-entry arithmetic up to alpha runs as packed fp32 (v_pk_*: two entries per instruction).
 		constexpr int QP = WAVE / 2 + 1;
-		__shared__ float4 s_q[6][QP];
-		__shared__ uint2 s_pp[QP];          // list position + 1 of the two entries (= n_contrib if it is the last contributor)
+		// row 6: list position + 1 of the two entries (= n_contrib if it is the last contributor) in .x / .y -- same stride as the
+		// other rows, so the loop addresses the whole queue with one base register and immediate offsets
+		__shared__ float4 s_q[7][QP];
 
 		const BlockId blk = block_of(blockIdx.x, ntiles);
 		if (blk.tile >= ntiles) return;
@@ -82,7 +83,7 @@ namespace fdgs
 				float* q5 = reinterpret_cast<float*>(&s_q[5][pr]) + h;
 				q0[0] = a.x; q0[2] = a.y; q1[0] = a.z; q1[2] = a.w; q2[0] = b.x; q2[2] = b.y;
 				q3[0] = b.z; q3[2] = b.w; q4[0] = c.x; q4[2] = c.y; q5[0] = c.z; q5[2] = c.w;
-				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[h] = (uint32_t)pos + 1u;
+				(reinterpret_cast<uint32_t*>(&s_q[6][pr]))[h] = (uint32_t)pos + 1u;
 			}
 			if (lane == 0 && (cnt & 1))
 			{
@@ -90,7 +91,7 @@ namespace fdgs
 				const int pr = cnt >> 1;
 #pragma unroll
 				for (int k = 0; k < 6; k++) { float* q = reinterpret_cast<float*>(&s_q[k][pr]) + 1; q[0] = 0.f; q[2] = 0.f; }
-				(reinterpret_cast<uint32_t*>(&s_pp[pr]))[1] = 0u;
+				(reinterpret_cast<uint32_t*>(&s_q[6][pr]))[1] = 0u;
 			}
 			__syncthreads(); // single-wave workgroup: orders the LDS writes before the cross-lane reads
 
@@ -102,7 +103,7 @@ namespace fdgs
 			for (int i = 0; i < npairs; i++)
 			{
 				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i], Q5 = s_q[5][i];
-				const uint2 pp = s_pp[i];
+				const uint2 pp = *reinterpret_cast<const uint2*>(&s_q[6][i]);
 				const v2f dx = v2f{ Q0.x, Q0.y } - pixfx, dy = v2f{ Q0.z, Q0.w } - pixfy;
 				const v2f cA = { Q1.x, Q1.y }, cB = { Q1.z, Q1.w }, cC = { Q2.x, Q2.y }, op = { Q2.z, Q2.w };
 				const v2f s2 = __builtin_elementwise_fma(cC * dy, dy, (cA * dx) * dx);
