@@ -8,7 +8,12 @@ per view:
     activations (exp / sigmoid / normalize; fused into the preprocess kernels, --reference-host: PyTorch) ->
     render forward (HIP) -> (1-l) L1 + l (1 - SSIM) (fused HIP kernel, --torch-loss: PyTorch conv2d) ->
     backward (HIP; gradients land directly in the flat bucket) ->
-then once per step: [N > 1: ONE all-reduce of the flat 161*P-float gradient bucket over RCCL] -> Adam step.
+then once per step the optimizer step (Adam, torch.optim.Adam arithmetic):
+    N = 1: the SH coefficients (89 % of the parameters) are updated straight from the views' staged SH gradients by one fused
+           kernel (fdgs_adam_step_sh), the 17 geometry floats per Gaussian by fdgs_adam_step;
+    N > 1: the exchange over RCCL first -- up to 16 views per step over all ranks: all-gather of the views' SH stages (32 B per
+           Gaussian and view) + all-reduce of the geometry gradients, then the same fused update on every rank; more views:
+           all-reduce of the flat 161*P-float gradient bucket, then Adam over it (--dense-sh-exchange forces this).
 Frames / timesteps shard embarrassingly: rank r renders timestamp (r + 0.5) / N of the sequence with
 replicated parameters (scaling = "weak": B views per GPU per step).  Inputs are synthetic
 (fdgs.synth, seed 0) and resident in HBM before the timed region.
