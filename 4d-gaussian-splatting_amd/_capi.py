@@ -40,7 +40,7 @@ class FdgsScene(C.Structure):
 
 class FdgsForwardOut(C.Structure):
     _fields_ = [("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
-                ("out_means3D", _fp), ("covs_com", _fp)]
+                ("out_means3D", _fp), ("covs_com", _fp), ("split_colour", C.c_int32)]
 
 
 class FdgsBackwardIn(C.Structure):

@@ -94,7 +94,7 @@ namespace
 		}
 	};
 	const char* const STAGE_NAMES[FDGS_NUM_STAGES] = { "preprocess_fwd", "tile_count", "tile_scan", "tile_scatter",
-		"tile_sort", "readback", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero", "sh_bwd" };
+		"tile_sort", "colour_fwd", "blend_fwd", "blend_bwd", "preprocess_bwd", "grad_zero", "sh_bwd" };
 }
 
 extern "C" int fdgs_profile_enable(int stage_mask) { g_prof_mask.store((uint32_t)stage_mask); return FDGS_OK; }
@@ -207,7 +207,31 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		return FDGS_OK;
 	}
 
-	STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, stream), "preprocess_fwd");
+	// split_colour: the SH colours are only needed by the blend -- they are evaluated on a second stream of this thread's while
+	// the binning runs on the caller's (event after the geometry launch, event back before the blend)
+	struct Aux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+	static thread_local Aux aux;
+	const bool split = out->split_colour != 0 && s.shs != nullptr && !debug;
+	if (split)
+	{
+		if (!aux.stream)
+		{
+			HIP_TRY(hipStreamCreateWithFlags(&aux.stream, hipStreamNonBlocking), "hipStreamCreate");
+			HIP_TRY(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming), "hipEventCreate");
+			HIP_TRY(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming), "hipEventCreate");
+		}
+		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, 1, stream), "preprocess_fwd (geometry)");
+		HIP_TRY(hipEventRecord(aux.fork, stream), "hipEventRecord");
+		HIP_TRY(hipStreamWaitEvent(aux.stream, aux.fork, 0), "hipStreamWaitEvent");
+		{
+			StageTimer timer__(FDGS_STAGE_COLOUR_FWD, aux.stream);
+			HIP_TRY(launch_preprocess_fwd(s, *out, geom, counters, 2, aux.stream), "preprocess_fwd (colour)");
+		}
+		HIP_TRY(hipEventRecord(aux.join, aux.stream), "hipEventRecord");
+	}
+	else
+		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, 0, stream), "preprocess_fwd");
+	bool joined = !split;   // the blend must not start before the colours are there
 	const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
 	const float* depths = (const float*)(geom + GL.depths);
 	STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
@@ -253,6 +277,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 			STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)capacity, stream), "tile scatter");
 		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, sort_longest, pairs, point_list, ranges,
 		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, stream), "tile sort");
+		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
 		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
 	};
@@ -306,6 +331,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		}
 		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");   // stream-ordered: after the sort, whether it was launched or not
 		HIP_TRY(sorted, "tile sort");
+		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
 		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
 	}

@@ -96,7 +96,8 @@ namespace fdgs
 
 	// ---- stage launchers (each enqueues on `stream`, returns hipError_t) ----
 
-	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, hipStream_t stream);
+	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, int part,
+	                                 hipStream_t stream);   // part 0: one launch; 1 / 2: geometry / colour halves
 
 	// Stable LSD radix sort of (key,value) u32 pairs on key bits [bit_lo, bit_hi) (radix_sort.hip; used by knn.hip).
 	// keys[0]/vals[0] hold the input; *result receives the index (0/1) of the buffers holding the output.

@@ -181,12 +181,17 @@ namespace fdgs
 		else stage_sh_block_scalar(tile, shs, g0, P, M, first_coeff, ncoeff, alive_mask, lane);
 	}
 
+	// PART 0: everything.  The forward can also run it in two launches (fdgs_forward_out.split_colour): PART 1 = the geometry
+	// (everything the tile binning needs; colour left at zero), PART 2 = the SH colour of the Gaussians PART 1 kept (radius > 0),
+	// on a second stream next to the binning -- same arithmetic, same results.
+	template <int PART>
 	__global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreArgs a)
 	{
 		// every lane stays until the end: the SH blocks are staged cooperatively per wave
 		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
 		// first kernel of the forward: clears the tile counters of the binning passes (more cells than Gaussians: stride)
-		for (int c = tid_g; c < a.bin_counter_words; c += gridDim.x * blockDim.x) a.bin_counters[c] = 0u;
+		if (PART != 2)
+			for (int c = tid_g; c < a.bin_counter_words; c += gridDim.x * blockDim.x) a.bin_counters[c] = 0u;
 		const bool valid = tid_g < a.P;
 		const int idx = valid ? tid_g : a.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
 
@@ -196,7 +201,17 @@ namespace fdgs
 		if (a.raw) opacity = act_sigmoid(opacity);
 		float cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 		bool alive = valid;
+		int radius = 0;
+		uint32_t tiles = 0;
+		ushort4 rect = make_ushort4(0, 0, 0, 0);
+		float depth = 0.0f;
+		float2 pix = make_float2(0.f, 0.f);
+		float3 conic = make_float3(0.f, 0.f, 0.f);
+		float3 rgb = make_float3(0.f, 0.f, 0.f);
+		uint8_t clampbits = 0;
 
+		if constexpr (PART == 2) alive = valid && a.radii[idx] > 0;   // what the geometry launch kept
+		else {
 		if (a.cov3D_precomp != nullptr)
 		{
 #pragma unroll
@@ -274,15 +289,6 @@ namespace fdgs
 			}
 		}
 
-		int radius = 0;
-		uint32_t tiles = 0;
-		ushort4 rect = make_ushort4(0, 0, 0, 0);
-		float depth = 0.0f;
-		float2 pix = make_float2(0.f, 0.f);
-		float3 conic = make_float3(0.f, 0.f, 0.f);
-		float3 rgb = make_float3(0.f, 0.f, 0.f);
-		uint8_t clampbits = 0;
-
 		if (alive)
 		{
 			const float3 p_view = xform4x3(p_orig, a.viewmatrix);
@@ -325,11 +331,13 @@ namespace fdgs
 			}
 		}
 
+		}   // PART != 2
+
 		if (a.colors_precomp != nullptr)
 		{
 			if (alive) rgb = ld3(a.colors_precomp, idx);
 		}
-		else
+		else if constexpr (PART != 1)
 		{
 			__shared__ float s_sh[256 / WAVE][WAVE * SH_STRIDE];
 			const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
@@ -373,6 +381,17 @@ namespace fdgs
 		}
 
 		if (!valid) return;
+		if constexpr (PART == 2)
+		{
+			// the colour words of the blend record (zero so far) and the clamp bits
+			if (alive)
+			{
+				float* rec = reinterpret_cast<float*>(a.records + 3 * (size_t)idx);
+				rec[6] = rgb.x; rec[7] = rgb.y; rec[8] = rgb.z;
+				a.clamped[idx] = clampbits;
+			}
+			return;
+		}
 		// ---- stores (every output written for every Gaussian) ----
 		a.radii[idx] = radius;
 		a.tiles_touched[idx] = tiles;
@@ -396,7 +415,9 @@ namespace fdgs
 		a.records[3 * (size_t)idx + 2] = make_float4(rgb.z, depth, flow.x, flow.y);
 	}
 
-	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, hipStream_t stream)
+	// part: 0 = one launch; 1 / 2 = the geometry / colour halves (see the kernel)
+	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, int part,
+	                                 hipStream_t stream)
 	{
 		const GeomLayout L = geom_layout(s.P);
 		PreArgs a;
@@ -422,7 +443,9 @@ namespace fdgs
 		a.clamped = reinterpret_cast<uint8_t*>(geom + L.clamped);
 		a.bin_counters = bin_counters;
 		a.bin_counter_words = (int)bin_counter_words(a.grid_x * a.grid_y);
-		hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		if (part == 1) hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		else if (part == 2) hipLaunchKernelGGL(preprocess_fwd_kernel<2>, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(preprocess_fwd_kernel<0>, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();
 	}
 

@@ -22,14 +22,15 @@ import torch
 from .gaussian_renderer.diff_gaussian_rasterization import GaussianRasterizationSettings, _C, _is_given
 
 
-def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var):
+def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
+                split_colour=False):
     """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple."""
     e = torch.Tensor([])
     args = (rs.bg, means3D, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
             rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
             rs.image_height, rs.image_width, sh, rs.sh_degree, rs.sh_degree_t, rs.campos, rs.timestamp,
             rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, rs.prefiltered, rs.debug)
-    return _C.rasterize_gaussians(*args, raw_params=True)
+    return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour)
 
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,

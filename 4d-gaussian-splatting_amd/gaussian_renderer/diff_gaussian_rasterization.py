@@ -112,10 +112,11 @@ class _NativeRasterizer:
     def rasterize_gaussians(self, bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
                             scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
-                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False):
+                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False):
         """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49).
-        ``raw_params`` (keyword-only extension): the scale / opacity / rotation tensors are the model's raw
-        parameters and the kernels apply the activations (fdgs_scene.raw_params)."""
+        Keyword-only extensions: ``raw_params``: the scale / opacity / rotation tensors are the model's raw
+        parameters and the kernels apply the activations (fdgs_scene.raw_params); ``split_colour``: the SH colour evaluation
+        runs on the library's second stream next to the tile binning (fdgs_forward_out.split_colour; forward-only rendering)."""
         if not means3D.is_cuda:
             raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
         dev = means3D.device
@@ -134,7 +135,7 @@ class _NativeRasterizer:
         out_means3D = torch.empty((P, 3), **fo)
         covs_com = torch.empty((P, 6), **fo)  # owning, not a from_blob alias of the scratch (rasterize_points.cu:144-147)
         out = _capi.FdgsForwardOut(out_color.data_ptr(), out_flow.data_ptr(), out_depth.data_ptr(), out_T.data_ptr(),
-                                   _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com))
+                                   _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com), int(bool(split_colour)))
         scratch = _Scratch(dev)
         R = C.c_int32(0)
         with torch.cuda.device(dev):

@@ -26,7 +26,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_sh_stages
 
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
-                 fuse_sh_adam: bool = True, gather_max_views: int = 16):
+                 fuse_sh_adam: bool = True, gather_max_views: int = 16, split_colour: bool = False):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -37,6 +37,7 @@ class StepPipeline:
         # Gaussian and view, all-gather) instead of all-reducing the dense SH gradient (12 M B per Gaussian), and every rank
         # runs the fused update on all of them (train_host.gather_sh_stages_begin); beyond it the dense all-reduce is cheaper
         self.gather_max_views = int(gather_max_views)
+        self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
         dev = model.flat.device
         self.dev = dev
         # (Tried and dropped, with measurements on MI355X: a high-priority F stream and a CU-masked B stream change
@@ -86,7 +87,7 @@ class StepPipeline:
                 rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
                     cams[b], m, pipe, bg, scaling_modifier)
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
-                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var)
+                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, split_colour=self.split_colour)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):

@@ -82,6 +82,9 @@ def parse_args():
                     help="fused kernels driven through autograd (render_raw + fused_l1_ssim + backward()) on one stream, "
                          "instead of the explicit two-stream step pipeline (fdgs/pipeline.py)")
     ap.add_argument("--no-overlap", action="store_true", help="step pipeline on a single stream (A/B for the overlap)")
+    ap.add_argument("--split-colour", choices=("forward", "all", "off"), default="forward",
+                    help="fdgs_forward_out.split_colour (SH colours on the library's second stream next to the binning): in the "
+                         "forward-only loop (default), also in the training step, or nowhere")
     ap.add_argument("--dense-sh-exchange", action="store_true",
                     help="N > 1: always all-reduce the dense SH gradient (default: up to 16 views per step over all ranks exchange "
                          "the views' 32-byte SH stages by all-gather instead, train_host.gather_sh_stages_begin)")
@@ -214,7 +217,7 @@ def main():
     if use_pipeline:
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
-                                gather_max_views=0 if args.dense_sh_exchange else 16)
+                                gather_max_views=0 if args.dense_sh_exchange else 16, split_colour=args.split_colour == "all")
 
     def step():
         if use_pipeline:
@@ -312,7 +315,8 @@ def main():
         if use_pipeline:  # the same explicit call the step pipeline makes (no autograd bookkeeping)
             from fdgs.fused import raw_forward, raw_settings
             rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
-            return raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv)
+            return raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
+                               split_colour=args.split_colour != "off")
         return render(c, model, pipe, bg) if args.reference_host else render_raw(c, model, pipe, bg)
 
     with torch.no_grad():
@@ -386,6 +390,7 @@ def main():
                    "num_rendered": int(round(R_timed)), "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,
                    "parallelism": "frame-parallel dp%d" % world, "mode": mode},
         "forward_mpix_s": round(world * n_fwd * N / dt_fwd / 1e6, 1),
+        "forward_split_colour": bool(use_pipeline and args.split_colour != "off"),
         "forward_ms": round(dt_fwd / n_fwd * 1e3, 4),
         "raster_ms": round(sum(v["ms"] for v in stages.values()), 4),
         "stages": stages,

@@ -121,6 +121,10 @@ typedef struct fdgs_forward_out
 	float* out_means3D;   /* [P,3]    means3D, shifted by the conditional mean where rot_4d */
 	float* covs_com;      /* [P,6] or NULL: owning copy of the computed 3D covariances
 	                         (zero for culled Gaussians; the reference returns uninitialised memory there) */
+	int32_t split_colour; /* 0: one preprocess launch.  1: geometry first, the SH -> RGB evaluation (the bulk of the preprocess'
+	                         memory traffic, which only the blend needs) on an internal second stream next to the tile binning
+	                         (events in and out): shortens the forward's critical path by ~30 us at C3 for forward-only
+	                         rendering; same arithmetic, bit-identical outputs */
 } fdgs_forward_out;
 
 /* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output
@@ -263,7 +267,7 @@ void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);
 #define FDGS_STAGE_TILE_SCAN 2
 #define FDGS_STAGE_TILE_SCATTER 3
 #define FDGS_STAGE_TILE_SORT 4
-#define FDGS_STAGE_READBACK 5  /* unused since the scan kernel writes R into a pinned host mailbox itself (kept for numbering) */
+#define FDGS_STAGE_COLOUR_FWD 5  /* the SH colour half of the preprocess when the forward runs it on its second stream (split_colour) */
 #define FDGS_STAGE_BLEND_FWD 6
 #define FDGS_STAGE_BLEND_BWD 7
 #define FDGS_STAGE_PREPROCESS_BWD 8

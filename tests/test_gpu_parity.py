@@ -354,6 +354,28 @@ def test_forward_run_ahead_matches_exact_path(gpu_device):
     assert longest[3] > 4096 > longest[2] + longest[2] // 4 and longest[1] > 2 * longest[0] and longest[4] < longest[3] // 8
 
 
+@pytest.mark.parametrize("cfg", [SC("s4", 20000, 320, 240, 3, 2, 0.03, 10.0, True, 4, False), SC("s3", 9000, 208, 160, 2, 0, 0.03, 1.0, False, 3, True),
+                                 SC("s0", 5000, 160, 128, 0, 0, 0.03, 1.0, True, 4, True)], ids=["4d-sh", "3d-sh", "deg0"])
+def test_split_colour_forward_is_bit_identical(cfg, gpu_device):
+    """fdgs_forward_out.split_colour: geometry and SH colour as two launches, the second on the library's own stream next to the
+    tile binning.  Same arithmetic: every forward output, the blend records and the clamp bits equal the one-launch forward bit
+    for bit; the backward that follows reads the same buffers."""
+    from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
+    from util import native_args_fwd, scene_to_device, collect_forward
+    scene = synth.make_scene(cfg, seed=61)
+    sc = scene_to_device(scene, gpu_device)
+    P, W, H = int(sc["means3D"].shape[0]), int(sc["W"]), int(sc["H"])
+    outs = []
+    for split in (False, True, True):   # twice: the second split call runs ahead of num_rendered
+        res = _C.rasterize_gaussians(*native_args_fwd(sc), split_colour=split)
+        outs.append(collect_forward(res, P, W, H))
+    for other in outs[1:]:
+        for key in ("R", "out_color", "out_flow", "out_depth", "out_T", "radii", "n_contrib", "final_T", "point_list", "ranges", "rgb",
+                    "clamped_bits", "conic_opacity", "means2D", "rec_depth", "rec_flow"):
+            np.testing.assert_array_equal(outs[0][key], other[key], err_msg="split_colour %s" % key)
+    assert (outs[0]["rgb"] != 0).any() and outs[0]["R"] > 0
+
+
 def test_binning_many_tiles_direct_path(gpu_device):
     """More tiles than an LDS histogram holds (> 36 864): count / scatter fall back to one global atomic per instance."""
     scene = synth.make_scene(SC("v", 3000, 3104, 3104, 0, 0, 0.02, 1.0, True, 4, True), seed=14)
