@@ -15,6 +15,6 @@ med = lambda xs: sorted(xs)[len(xs) // 2]
 keys = list(res[libs[0]][0]["stages"].keys())
 print("%-16s" % "stage", *["%24s" % os.path.basename(l) for l in libs])
 for k in keys:
-    print("%-16s" % k, *["%24.4f" % med([d["stages"][k]["ms"] for d in res[l]]) for l in libs])
+    print("%-16s" % k, *["%24.4f" % med([d["stages"].get(k, {"ms": 0.0})["ms"] for d in res[l]]) for l in libs])
 for k in ("forward_ms", "ms_per_image", "value"):
     print("%-16s" % k, *["%24.4f" % med([d[k] for d in res[l]]) for l in libs])
