@@ -210,8 +210,9 @@ def main():
             for b in range(B)]
     cam = cams[0]
     bg = scene["bg"].to(dev)
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(dev) for _ in range(B)]
+    # one target per GLOBAL view index: N ranks x B views see the same data as one rank x N B views
+    gts = [torch.rand(3, scene["H"], scene["W"], generator=torch.Generator(device="cpu").manual_seed(1234 + rank * B + b)).to(dev)
+           for b in range(B)]
     sink = None if args.reference_host else model.grad_sink()
     use_pipeline = not (args.reference_host or args.autograd or args.torch_loss or args.no_loss)
     if use_pipeline:
@@ -329,6 +330,8 @@ def main():
         torch.cuda.synchronize(dev)
         dt_fwd = max_over_ranks(time.perf_counter() - t1, world, dev)
 
+    # digest of the parameters after all steps (tests compare N ranks x B views with one rank x N B views: the same update)
+    param_digest = [float(model.flat.double().sum()), float(model.flat.double().abs().sum())]
     # frame-parallel replicas must hold bit-identical parameters after the timed steps (every rank applied the same update)
     replicas_identical = None
     if world > 1:
@@ -382,7 +385,7 @@ def main():
         "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4),
         "ms_per_image": round(dt / (args.steps * B) * 1e3, 4),
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,

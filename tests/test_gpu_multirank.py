@@ -38,3 +38,29 @@ def test_bench_two_ranks_share_one_gpu(views, dense, gpu_device):
     assert d["config"]["views_per_step_per_gpu"] == views and d["config"]["global_batch"] == 2 * views
     assert "roofline" in d and d["roofline"]["frac"] > 0
     assert d["replicas_identical"] is True   # both ranks hold bit-identical parameters after the steps
+
+
+def _run_bench(nproc, views, extra=()):
+    env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--workload", "C2",
+              "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0"] + list(extra)
+    if nproc == 1:
+        cmd = [sys.executable] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + common
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_two_ranks_make_the_same_update_as_one(dense, gpu_device):
+    """2 ranks x 2 views per step must train like 1 rank x 4 views: the same four timestamps per step, the same loss scale,
+    the exchanged gradient = the accumulated one (float atomics and the order of a few sums aside).  Both exchanges: the SH
+    stages gathered and fed to the fused update on every rank, and the dense bucket all-reduced."""
+    one = _run_bench(1, 4)
+    two = _run_bench(2, 2, ["--dense-sh-exchange"] if dense else [])
+    assert two["replicas_identical"] is True and two["config"]["global_batch"] == one["config"]["global_batch"] == 4
+    (s1, a1), (s2, a2) = one["param_digest"], two["param_digest"]
+    assert abs(a1 - a2) <= 1e-5 * a1 and abs(s1 - s2) <= 1e-5 * a1, (one["param_digest"], two["param_digest"])
