@@ -6,9 +6,11 @@ The reference finds them exactly (Morton order + 1024-point boxes, pruned with a
 result does not depend on the search order; what has to match is the arithmetic: ``d.x*d.x + d.y*d.y + d.z*d.z`` in
 float32 (:134-135) and ``(best[0] + best[1] + best[2]) / 3.0f`` with best[] ascending (:191).
 
-Parity pin: the CUDA source needs cub / thrust and cannot be built here, and the reference ships no fixtures for it;
-tests/test_oracle_knn.py checks this restatement against an independent exact nearest-neighbour search
-(scipy cKDTree in float64).  Only tests may import this module.
+Parity pin: tests/test_oracle_knn.py checks this restatement bit for bit against the reference's OWN device code
+(simple_knn.cu:28-191 -- coord2Morton, boxMinMax under the fiber block emulator, boxMeanDist -- compiled verbatim into
+oracle/_ref/liboracle_ref.so by oracle/refbuild/build_ref.py; only the host function :193-220, which needs cub / thrust, is
+restated with std:: in oracle/refbuild/ref_knn.cpp) and against an independent exact nearest-neighbour search (scipy
+cKDTree in float64).  Only tests may import this module.
 """
 import numpy as np
 

@@ -256,3 +256,18 @@ def mark_visible(means3D, viewmatrix, projmatrix, kind="port"):
 
 def threads(kind="port"):
     return int(_load(kind).oracle_threads())
+
+
+def ref_dist2_knn3(points):
+    """simple-knn's distCUDA2 through the reference's OWN device code (simple_knn.cu:28-191 compiled verbatim into
+    oracle/_ref/liboracle_ref.so, oracle/refbuild/ref_knn.cpp; contraction off): [P,3] float32 -> [P] float32."""
+    lib = _load("reference")
+    lib.oracle_ref_dist2_knn3.argtypes = [C.c_int, _F, _F]
+    lib.oracle_ref_dist2_knn3.restype = C.c_int
+    p = np.ascontiguousarray(np.asarray(points, dtype=np.float32))
+    assert p.ndim == 2 and p.shape[1] == 3
+    out = np.zeros((p.shape[0],), np.float32)   # spatial.cu:22 torch::full({P}, 0.0)
+    rc = lib.oracle_ref_dist2_knn3(p.shape[0], _ptr(p, C.c_float), _ptr(out, C.c_float))
+    if rc != 0:
+        raise RuntimeError("oracle_ref_dist2_knn3 failed: %d" % rc)
+    return out

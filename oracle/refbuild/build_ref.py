@@ -3,7 +3,8 @@
 
 Compiles the *reference's own* kernel source for the CPU: reads
 forward.cu / backward.cu / rasterizer_impl.cu in place from
-/root/reference/diff-gaussian-rasterization/cuda_rasterizer, cuts each file
+/root/reference/diff-gaussian-rasterization/cuda_rasterizer and simple_knn.cu from
+/root/reference/simple-knn, cuts each file
 just before its first host launcher (the only non-C++ syntax in them is the
 `<<<...>>>` launch), drops the cut text into a *temporary* build directory
 outside the repository, and compiles it with g++ -ffp-contract=off against the
@@ -30,6 +31,8 @@ CUTS = {
     "backward.cu": ("void BACKWARD::preprocess(", "backward_trunc.inc"),
     "rasterizer_impl.cu": ("void CudaRasterizer::Rasterizer::markVisible(", "impl_trunc.inc"),
 }
+# simple-knn (distCUDA2): the device code up to the host function that needs cub / thrust (simple_knn.cu:193)
+KNN_CUT = ("simple_knn.cu", "void SimpleKNN::knn(", "knn_trunc.inc")
 
 
 def main():
@@ -54,10 +57,18 @@ def main():
                 raise RuntimeError("marker %r not found in %s" % (marker, name))
             with open(os.path.join(tmp, inc), "w") as f:
                 f.write(text[:cut])
-        srcs = ["ref_emu.cpp", "ref_fwd.cpp", "ref_bwd.cpp", "ref_impl.cpp", "ref_api.cpp"]
+        knn = os.path.join(args.reference, "simple-knn")
+        with open(os.path.join(knn, KNN_CUT[0])) as f:
+            text = f.read()
+        cut = text.find(KNN_CUT[1])
+        if cut < 0:
+            raise RuntimeError("marker %r not found in %s" % (KNN_CUT[1], KNN_CUT[0]))
+        with open(os.path.join(tmp, KNN_CUT[2]), "w") as f:
+            f.write(text[:cut])
+        srcs = ["ref_emu.cpp", "ref_fwd.cpp", "ref_bwd.cpp", "ref_impl.cpp", "ref_api.cpp", "ref_knn.cpp"]
         cmd = ["g++", "-std=c++17", args.opt, "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-w",
                "-I", os.path.join(HERE, "shim"), "-I", HERE, "-I", tmp, "-I", cr,
-               "-I", os.path.join(dgr, "third_party", "glm"),
+               "-I", os.path.join(dgr, "third_party", "glm"), "-I", knn,
                "-o", out] + [os.path.join(HERE, s) for s in srcs]
         subprocess.check_call(cmd)
     finally:

@@ -32,7 +32,7 @@ namespace refemu
 			ids[t].block_idx = block_idx;
 			ids[t].thread_idx = dim3(t % block_dim.x, (t / block_dim.x) % block_dim.y, t / (block_dim.x * block_dim.y));
 			ids[t].block_rank = (unsigned)t;
-			ids[t].grid_rank = 0;
+			ids[t].grid_rank = (unsigned long long)block_idx.x * (unsigned)n + (unsigned)t;   // 1-D grids (simple-knn's boxMinMax); the render kernels do not read it
 			getcontext(&ctx[t]);
 			ctx[t].uc_stack.ss_sp = &stacks[(size_t)t * STACK_BYTES];
 			ctx[t].uc_stack.ss_size = STACK_BYTES;

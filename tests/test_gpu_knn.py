@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import util  # noqa: F401
-from oracle import knn_oracle
+from oracle import knn_oracle, pyoracle
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,18 @@ def test_dist2_bit_exact_vs_oracle(P, kind, gpu_device):
     got = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
     want = knn_oracle.dist2_knn3(pts)
     assert got.shape == want.shape == (P,)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.skipif(not pyoracle.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("P,kind", [(1, "gauss"), (3, "gauss"), (4, "gauss"), (255, "gauss"), (1025, "shifted"), (4097, "dups"),
+                                    (20000, "gauss"), (60000, "gauss")])
+def test_dist2_bit_exact_vs_reference_source(P, kind, gpu_device):
+    """knn.hip against the reference's own simple_knn.cu device code compiled for the CPU (oracle/_ref, ref_knn.cpp)."""
+    from fdgs.knn import distCUDA2
+    pts = _pts(P, 7 * P + 1, kind)
+    got = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
+    want = pyoracle.ref_dist2_knn3(pts)
     np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
