@@ -122,6 +122,10 @@ int oracle_mark_visible(int P, const float* means3D, const float* viewmatrix,
                         const float* projmatrix, uint8_t* present);
 /* Frees the lib-malloc arrays of io. */
 void oracle_free(oracle_io* io);
+/* Port oracle only (test helper for the block cull): out[i] = some pixel centre of tuple i's rectangle passes the forward
+ * blend's per-pixel test (forward.cu:585-590) in this oracle's arithmetic.  tuples [n][10] = mean x, y, conic xx, xy, yy,
+ * opacity, rx0, rx1, ry0, ry1. */
+int oracle_block_any_pixel_passes(int n, const float* tuples, uint8_t* out);
 /* "port" or "reference" */
 const char* oracle_kind(void);
 /* Number of OS threads the oracle uses (OpenMP). */

@@ -271,3 +271,16 @@ def ref_dist2_knn3(points):
     if rc != 0:
         raise RuntimeError("oracle_ref_dist2_knn3 failed: %d" % rc)
     return out
+
+
+def block_any_pixel_passes(tuples):
+    """Port oracle: per tuple [x, y, conic xx, xy, yy, opacity, rx0, rx1, ry0, ry1], does any pixel centre of the rectangle pass
+    the forward blend's per-pixel test (forward.cu:585-590) in the oracle's own fp32 arithmetic."""
+    lib = _load("port")
+    lib.oracle_block_any_pixel_passes.argtypes = [C.c_int, _F, _U8]
+    lib.oracle_block_any_pixel_passes.restype = C.c_int
+    t = np.ascontiguousarray(np.asarray(tuples, dtype=np.float32))
+    assert t.ndim == 2 and t.shape[1] == 10
+    out = np.zeros((t.shape[0],), np.uint8)
+    lib.oracle_block_any_pixel_passes(t.shape[0], _ptr(t, C.c_float), _ptr(out, C.c_uint8))
+    return out.astype(bool)
