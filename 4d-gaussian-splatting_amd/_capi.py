@@ -71,7 +71,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
@@ -108,6 +108,8 @@ def _load():
     lib.fdgs_debug_block_reaches.restype = C.c_int
     lib.fdgs_debug_run_ahead_stats.argtypes = [C.POINTER(C.c_int64)]
     lib.fdgs_debug_run_ahead_stats.restype = None
+    lib.fdgs_debug_clock_sample.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+    lib.fdgs_debug_clock_sample.restype = C.c_int
     lib.fdgs_sh_flush.argtypes = [C.c_int32] * 8 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.fdgs_sh_flush.restype = C.c_int
     lib.fdgs_profile_enable.argtypes = [C.c_int]
@@ -240,6 +242,28 @@ def run_ahead_stats():
     a = (C.c_int64 * 3)()
     lib.fdgs_debug_run_ahead_stats(a)
     return tuple(int(x) for x in a)
+
+
+class ClockSample:
+    """Shader clock sustained over an interval (fdgs_debug_clock_sample): start() enqueues the one-wave sampler on its own stream,
+    ghz() waits for it and returns the measured clock in GHz."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.stream = torch.cuda.Stream(device)
+        self.out = torch.zeros(5, dtype=torch.int64, device=device)
+
+    def start(self, span_ms: float):
+        with torch.cuda.device(self.dev):
+            rc = lib.fdgs_debug_clock_sample(self.out.data_ptr(), float(span_ms), C.c_void_p(self.stream.cuda_stream))
+        _check(rc, "fdgs_debug_clock_sample")
+
+    def ghz(self):
+        self.stream.synchronize()
+        w0, s0, w1, s1, khz = [int(x) for x in self.out.cpu().tolist()]
+        if w1 <= w0 or khz <= 0:
+            return None
+        return (s1 - s0) / (w1 - w0) * khz * 1e-6
 
 
 def current_stream_handle(device):

@@ -438,6 +438,35 @@ extern "C" int fdgs_debug_block_reaches(int32_t n, const float* tuples, uint8_t*
 	return FDGS_OK;
 }
 
+// One wave that notes (constant-rate wall clock, shader clock) at its start and again `span` wall ticks later: the ratio is the
+// shader clock the chip actually sustained over that interval -- under whatever load the other streams put on it.
+__global__ void clock_sample_kernel(unsigned long long* out, unsigned long long span, unsigned long long wall_khz)
+{
+	const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+	unsigned long long r1 = r0;
+	while (r1 - r0 < span)
+	{
+		__builtin_amdgcn_s_sleep(64);
+		r1 = __builtin_amdgcn_s_memrealtime();
+	}
+	const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+	out[0] = r0; out[1] = c0; out[2] = r1; out[3] = c1; out[4] = wall_khz;
+}
+
+extern "C" int fdgs_debug_clock_sample(uint64_t* out5, double span_ms, void* stream_v)
+{
+	g_err[0] = 0;
+	if (!out5 || !(span_ms > 0.0) || span_ms > 2000.0) return fail(FDGS_ERR_INVALID_ARG, "fdgs_debug_clock_sample: bad arguments");
+	int dev = 0, khz = 0;
+	HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+	HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev), "hipDeviceGetAttribute(WallClockRate)");
+	if (khz <= 0) return fail(FDGS_ERR_UNSUPPORTED, "no wall clock rate reported");
+	hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_v, (unsigned long long*)out5,
+	                   (unsigned long long)(span_ms * (double)khz), (unsigned long long)khz);
+	HIP_TRY(hipGetLastError(), "clock sample");
+	return FDGS_OK;
+}
+
 extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
                                 const void* geom_v, const void* bin_v, const void* img_v, fdgs_debug_view* v)
 {

@@ -35,6 +35,10 @@ CONFIGS: Dict[str, SceneConfig] = {
     "C2": SceneConfig("C2", 100_000, 800, 800, 3, 0, 0.02, 1.0, True, 4, True),
     "C3": SceneConfig("C3", 300_000, 1352, 1014, 3, 2, 0.015, 10.0, True, 4, False),
     "C5": SceneConfig("C5", 2_000_000, 2704, 2028, 3, 0, 0.006, 1.0, True, 4, True),
+    # not a BASELINE config -- a scaling probe: C3 with 4 x the Gaussians on 4 x the image area at the same footprint per
+    # Gaussian (focal doubles with W, so s0 halves): every per-tile quantity equals C3's, every launch is 4 x larger --
+    # what one launch per stage for 4 views of C3 would look like (tools/probe/README.md)
+    "C3x4": SceneConfig("C3x4", 1_200_000, 2704, 2028, 3, 2, 0.0075, 10.0, True, 4, False),
 }
 
 

@@ -140,6 +140,50 @@ class GaussianParams:
                 "dL_dscales_t": g["_scaling_t"], "dL_drotations_r": g["_rotation_r"]}
 
 
+class ReferenceStyleModel:
+    """The model a user of the REFERENCE holds when they swap in this package's ``render`` and nothing else: separate
+    ``nn.Parameter``s incl. ``_features_dc`` [P,1,3] / ``_features_rest`` [P,M-1,3] concatenated by ``get_features`` on every call,
+    PyTorch activations in the getters (scene/gaussian_model.py:179-219), ``torch.optim.Adam(lr=0, eps=1e-15)`` over one param
+    group per tensor (:331-357).  bench.py's drop-in leg times ``render()`` + autograd + this optimizer on it; nothing else uses it."""
+
+    def __init__(self, scene: Dict[str, object], device):
+        M = int(scene["M"])
+        mk = lambda t: torch.nn.Parameter(t.to(device).float().contiguous().requires_grad_(True))  # noqa: E731
+        self._xyz = mk(scene["means3D"])
+        self._features_dc = mk(scene["shs"][:, :1, :])
+        self._features_rest = mk(scene["shs"][:, 1:, :])
+        self._opacity = mk(_inv_sigmoid(scene["opacities"].clamp(1e-6, 1 - 1e-6)).reshape(-1, 1))
+        self._scaling = mk(torch.log(scene["scales"]))
+        self._rotation = mk(scene["rotations"])
+        self._t = mk(scene["ts"].reshape(-1, 1))
+        self._scaling_t = mk(torch.log(scene["scales_t"]).reshape(-1, 1))
+        self._rotation_r = mk(scene["rotations_r"])
+        self.active_sh_degree, self.active_sh_degree_t = int(scene["sh_degree"]), int(scene["sh_degree_t"])
+        self.time_duration = [0.0, float(scene["time_duration"])]
+        self.rot_4d, self.gaussian_dim = bool(scene["rot_4d"]), int(scene["gaussian_dim"])
+        self.force_sh_3d = bool(scene["force_sh_3d"])
+        self.prefilter_var = -1.0
+        self.env_map = None
+        self.get_max_sh_channels = M
+        groups = [dict(params=[self._xyz], lr=1.6e-4, name="xyz"), dict(params=[self._features_dc], lr=2.5e-3, name="f_dc"),
+                  dict(params=[self._features_rest], lr=2.5e-3 / 20.0, name="f_rest"), dict(params=[self._opacity], lr=5e-2, name="opacity"),
+                  dict(params=[self._scaling], lr=5e-3, name="scaling"), dict(params=[self._rotation], lr=1e-3, name="rotation")]
+        if self.gaussian_dim == 4:
+            groups += [dict(params=[self._t], lr=1.6e-4, name="t"), dict(params=[self._scaling_t], lr=5e-3, name="scaling_t")]
+            if self.rot_4d:
+                groups.append(dict(params=[self._rotation_r], lr=1e-3, name="rotation_r"))
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    get_xyz = property(lambda s: s._xyz)
+    get_t = property(lambda s: s._t)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_scaling_t = property(lambda s: torch.exp(s._scaling_t))
+    get_rotation = property(lambda s: F.normalize(s._rotation))
+    get_rotation_r = property(lambda s: F.normalize(s._rotation_r))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+
 class FlatAdam:
     """torch.optim.Adam(lr=0, eps=1e-15) semantics (scene/gaussian_model.py:353) over the flat bucket.
 
@@ -267,6 +311,8 @@ def allreduce_gradients(model: GaussianParams, world_size: int, average: bool = 
 def _bounds(begin: int, end: int, pieces: int):
     """[begin, end) cut into at most ``pieces`` runs whose starts are multiples of 4 elements (the Adam kernel's float4 path)."""
     n = end - begin
+    if n <= 0:
+        return []   # e.g. P == 0 after everything was pruned
     pieces = max(1, min(int(pieces), n))
     step = -(-n // pieces)
     step += (-step) % 4

@@ -47,7 +47,11 @@ ALGO_BYTES = {
     "blend_fwd": lambda P, Pv, M, R, N, T: 52 * R + 32 * N,
     "blend_bwd": lambda P, Pv, M, R, N, T: 96 * R + 36 * N,
     # BASELINE.md's preprocess-bwd figure (68 + 24 M + 150) P_v + cov2D-bwd 104 P_v, split over our two kernels:
-    "sh_bwd": lambda P, Pv, M, R, N, T: (24 * M + 44) * Pv,
+    # sh_bwd per mode; Pv here = the LIVE Gaussians (those that carry a colour gradient): the kernel scans
+    # the colour words of all P records and evaluates the live ones only.  Direct: dL_dsh rows read-modify-written;
+    # deferred (sh_stage): the row is only read, 32 B of stage written instead
+    "sh_bwd": lambda P, Pv, M, R, N, T: 12 * P + (24 * M + 44) * Pv,
+    "sh_bwd_deferred": lambda P, Pv, M, R, N, T: 12 * P + (12 * M + 76) * Pv,
     "preprocess_bwd": lambda P, Pv, M, R, N, T: (68 + 150 + 104 + 64 - 44) * Pv,  # incl. the fused cov2D backward + record read
     # tile binning (csrc/tilebin.hip): count reads the rectangles, scatter writes one (depth bits, id) pair per instance,
     # the per-tile local sort reads the pairs and writes point_list + ranges
@@ -65,7 +69,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20,
                     help="untimed steps before anything is measured (the shader clock takes ~100 ms of load to settle)")
-    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5", "C3x4"])
     ap.add_argument("--views-per-step", type=int, default=4,
                     help="views rendered per rank and optimizer step.  4 (default): the reference's DyNeRF batch per GPU "
                          "(configs/dynerf/*.yaml:7; gradients accumulated, train.py:104-166), weak scaling: global batch "
@@ -74,6 +78,10 @@ def parse_args():
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--host-cost-steps", type=int, default=30,
                     help="steps of the tiny-scene leg that measures the host cost per view (0 = skip, e.g. under rocprofv3)")
+    ap.add_argument("--dropin-steps", type=int, default=3,
+                    help="N = 1 only: steps of the DROP-IN leg -- a reference-style model (separate parameters, torch.cat features, "
+                         "PyTorch activations, torch.optim.Adam over 9 groups) through this package's render() + autograd + the "
+                         "reference's PyTorch loss: what a user of the reference gets by swapping one import (0 = skip)")
     ap.add_argument("--no-loss", action="store_true", help="debug: sum() loss instead of L1 + SSIM")
     ap.add_argument("--reference-host", action="store_true",
                     help="host side exactly as the reference: render() on PyTorch activations, autograd gradient accumulation")
@@ -91,13 +99,33 @@ def parse_args():
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec through torch.distributed.run (one process per GPU, RCCL),
+    rendezvous on 127.0.0.1 with a free port.  Returns the children's exit code."""
+    import socket
+    import subprocess
+    share = bool(os.environ.get("FDGS_BENCH_DEBUG_SHARE_GPU"))
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (see docstring)" % args.gpus)
+    if args.gpus != world and world > 1:
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -108,9 +136,13 @@ def init_dist(args):
             torch.cuda.set_device(0)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
+            if torch.cuda.device_count() <= local:
+                raise SystemExit("bench.py: rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    return world, rank, local
+        backend = dist.get_backend()
+        assert dist.get_world_size() == world
+    return world, rank, local, backend
 
 
 def barrier(world):
@@ -147,6 +179,71 @@ def cpu_baseline(scene, samples):
     return {"value": samples / dt, "unit": "images/s", "cores": pyoracle.threads("port"), "kind": "port",
             "sample": "%d rasterizer forward+backward passes of the same %s scene (%.1f s of CPU work); "
                       "oracle/fdgs_oracle.c, gcc -O2 -fopenmp" % (samples, scene["cfg"].name, dt)}
+
+
+def dropin_leg(args, scene, cams, gts, pipe, bg, dev, B):
+    """What a user of the reference gets by swapping ONE import (gaussian_renderer.render / GaussianRasterizer -> this package) and
+    keeping everything else of train.py:104-170, 247-249: a reference-style model (separate parameters, torch.cat'ed features,
+    PyTorch activations), render() through autograd, the reference's PyTorch L1 + SSIM (utils/loss_utils.py), torch.optim.Adam over
+    the reference's param groups, zero_grad(set_to_none=True).  Also the pieces, timed one by one, so that the gap to the step
+    pipeline (`value`) can be attributed."""
+    from fdgs import train_host
+    from fdgs.gaussian_renderer import render
+    from fdgs.loss import fused_l1_ssim
+    rm = train_host.ReferenceStyleModel(scene, dev)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / n * 1e3
+
+    def step(loss_fn):
+        for b in range(B):
+            pkg = render(cams[b], rm, pipe, bg)
+            loss = loss_fn(pkg["render"], gts[b])
+            (loss / B).backward()                       # train.py:162
+        rm.optimizer.step()                             # train.py:247-249
+        rm.optimizer.zero_grad(set_to_none=True)
+
+    n = max(1, args.dropin_steps)
+    ms_step = timed(lambda: step(train_host.photometric_loss), n)
+    ms_step_fused = timed(lambda: step(lambda a, g: fused_l1_ssim(a, g, 0.2)), n)
+
+    def fwd():
+        with torch.no_grad():
+            render(cams[0], rm, pipe, bg)
+
+    def fwd_bwd():
+        pkg = render(cams[0], rm, pipe, bg)
+        (pkg["render"].sum() * 1e-6).backward()
+        rm.optimizer.zero_grad(set_to_none=True)
+
+    img = torch.rand(3, scene["H"], scene["W"], device=dev)
+
+    def torch_loss():
+        x = img.clone().requires_grad_(True)
+        train_host.photometric_loss(x, gts[0]).backward()
+
+    def optim():
+        for g in rm.optimizer.param_groups:
+            for q in g["params"]:
+                if q.grad is None:
+                    q.grad = torch.zeros_like(q)
+        rm.optimizer.step()
+
+    ms_fwd, ms_fb, ms_loss, ms_opt = timed(fwd, 8), timed(fwd_bwd, 4), timed(torch_loss, 4), timed(optim, 3)
+    rm.optimizer.zero_grad(set_to_none=True)
+    return {"images_s": round(B * 1e3 / ms_step, 2), "ms_per_image": round(ms_step / B, 4), "forward_ms": round(ms_fwd, 4),
+            "images_s_with_fused_loss": round(B * 1e3 / ms_step_fused, 2),
+            "pieces_ms": {"render_forward": round(ms_fwd, 4), "render_forward_backward_autograd": round(ms_fb, 4),
+                          "pytorch_l1_ssim_forward_backward": round(ms_loss, 4), "torch_adam_step_per_step": round(ms_opt, 4)},
+            "steps": n,
+            "what": "reference-style model + render() + autograd + PyTorch L1/SSIM (utils/loss_utils.py) + torch.optim.Adam (9 groups): "
+                    "the reference's train.py:104-170 with one import swapped; images_s_with_fused_loss: the same with fdgs.loss.fused_l1_ssim"}
 
 
 def pmc_traffic(stage):
@@ -188,7 +285,10 @@ def pmc_valu(stage):
 
 def main():
     args = parse_args()
-    world, rank, local = init_dist(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called as the driver calls the N = 1 bench: launch the N ranks ourselves
+        raise SystemExit(self_launch(args))
+    world, rank, local, backend = init_dist(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
     dev = torch.device("cuda", local)
@@ -273,10 +373,24 @@ def main():
     _capi.profile_enable(True, stages=[dom])
     _R_LOG.clear()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # shader clock actually sustained during the timed steps: a one-wave sampler on its own stream spans ~80 % of the region
+    # (its length estimated from two more untimed steps)
+    torch.cuda.synchronize(dev)
+    te = time.perf_counter()
+    step(); step()
+    torch.cuda.synchronize(dev)
+    est_ms = (time.perf_counter() - te) / 2 * 1e3 * args.steps
+    clock = None
+    try:
+        clock = _capi.ClockSample(dev)
+    except Exception:
+        clock = None
     torch.cuda.synchronize(dev)
     barrier(world)
     t0 = time.perf_counter()
     marks[0].record()
+    if clock is not None:
+        clock.start(min(max(0.8 * est_ms, 1.0), 1500.0))
     for i in range(args.steps):
         pkg = step()
         marks[i + 1].record()
@@ -284,6 +398,11 @@ def main():
     barrier(world)
     dt = time.perf_counter() - t0
     _capi.profile_enable(False)
+    shader_ghz = None
+    try:
+        shader_ghz = clock.ghz() if clock is not None else None
+    except Exception:
+        shader_ghz = None
     prof_dom = _capi.profile_read()[dom]
     dt = max_over_ranks(dt, world, dev)
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -330,6 +449,40 @@ def main():
         torch.cuda.synchronize(dev)
         dt_fwd = max_over_ranks(time.perf_counter() - t1, world, dev)
 
+    # rasterizer-only rate: forward + backward of one view after the other, no loss, no optimizer -- the like-for-like partner of
+    # cpu_baseline (same scene, the same four upstream gradients, all of them given: the general blend-backward variant)
+    raster = None
+    if use_pipeline and world == 1:
+        from fdgs.fused import raw_backward, raw_forward, raw_settings
+        up4 = synth.make_upstream_grads(scene["W"], scene["H"], seed=1, scale=1e-2)
+        up4 = {k: v.to(dev) for k, v in up4.items()}
+        gacc = torch.zeros((model.P, 16), dtype=torch.float32, device=dev)
+        sink4 = model.grad_sink()
+
+        def raster_only(c):
+            rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
+            (R, color, flow, depth, T, radii, geom, binb, img, _c, om) = raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t,
+                                                                                    rotation, rotation_r, pv)
+            raw_backward(rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img,
+                         up4["grad_color"], up4["grad_depth"], up4["grad_alpha"], up4["grad_flow"], sink4, False, grad_accum=gacc)
+
+        with torch.no_grad():
+            for b in range(B):
+                raster_only(cams[b])
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            for i in range(n_fwd):
+                raster_only(cams[i % B])
+            torch.cuda.synchronize(dev)
+            dt_r = time.perf_counter() - t2
+        raster = {"images_s": round(n_fwd / dt_r, 2), "ms_per_image": round(dt_r / n_fwd * 1e3, 4),
+                  "what": "rasterizer forward + backward only (all four upstream gradients given), one stream, %d views: pairs with cpu_baseline" % n_fwd}
+        del gacc, up4
+
+    dropin = None
+    if world == 1 and rank == 0 and args.dropin_steps > 0:
+        dropin = dropin_leg(args, scene, cams, gts, pipe, bg, dev, B)
+
     # digest of the parameters after all steps (tests compare N ranks x B views with one rank x N B views: the same update)
     param_digest = [float(model.flat.double().sum()), float(model.flat.double().abs().sum())]
     # frame-parallel replicas must hold bit-identical parameters after the timed steps (every rank applied the same update)
@@ -348,13 +501,21 @@ def main():
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     # visible Gaussians: mean over the views of the last step (every view has its own timestamp, hence its own cull)
     Pv = sum(int((r["radii"] > 0).sum().item()) for r in pkg) / len(pkg)
+    # live Gaussians: those that contributed to some pixel (a non-zero screen-space gradient row), mean over the last step's views
+    if use_pipeline:
+        P_live = sum(int((r["viewspace_grad"] != 0).any(dim=1).sum().item()) for r in pkg) / len(pkg)
+    else:
+        P_live = Pv
     stages = {}
     for name, (ms, n) in prof_all.items():
         if n == 0:
             continue
         entry = {"ms": round(ms / n, 4)}
         if name in ALGO_BYTES:
-            b = ALGO_BYTES[name](P, Pv, M, R_stage, N, T)
+            if name == "sh_bwd":   # the step pipeline stages the SH gradient (deferred) whenever it is used; bytes scale with the LIVE Gaussians
+                b = ALGO_BYTES["sh_bwd_deferred" if use_pipeline else "sh_bwd"](P, P_live, M, R_stage, N, T)
+            else:
+                b = ALGO_BYTES[name](P, Pv, M, R_stage, N, T)
             entry["algo_bytes"] = int(b)
             entry["gbps"] = round(b / (ms / n * 1e-3) / 1e9, 1) if ms > 0 else None
         stages[name] = entry
@@ -368,12 +529,17 @@ def main():
                 "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
                         "peak is reported as the contract asks; valu_issue_frac = VALU issue cycles per SIMD (SQ counters, "
-                        "profiles/) / kernel cycles at the 2.4 GHz maximum clock is the bound this kernel actually runs against"}
+                        "profiles/) / kernel cycles at the shader clock measured during the timed steps is the bound this kernel actually runs against"}
     valu = pmc_valu(dom) if cfg.name == "C3" else None   # the committed SQ-counter pass is a C3 pass
+    roofline["shader_clock_ghz_measured"] = None if shader_ghz is None else round(shader_ghz, 3)
     if valu:
-        valu["kernel_cycles_at_2.4GHz"] = int(dom_ms * 1e-3 * 2.4e9)
+        # instruction counts are a property of the kernel + workload (committed SQ pass, same C3 scene); the time and the clock are live
+        ghz = shader_ghz if shader_ghz else 2.4
+        valu["kernel_cycles"] = int(dom_ms * 1e-3 * ghz * 1e9)
+        valu["clock"] = ("measured during the timed steps (s_memtime / s_memrealtime sampler, fdgs_debug_clock_sample)" if shader_ghz
+                         else "2.4 GHz maximum clock assumed: valu_issue_frac is a LOWER bound")
         roofline["valu"] = valu
-        roofline["valu_issue_frac"] = round(valu["valu_issue_cycles_per_simd"] / max(valu["kernel_cycles_at_2.4GHz"], 1), 3)
+        roofline["valu_issue_frac"] = round(valu["valu_issue_cycles_per_simd"] / max(valu["kernel_cycles"], 1), 3)
     mode = ("weak scaling, %d views per GPU and step (the reference's DyNeRF batch per GPU)" % B if B > 1 else
             "BASELINE configs[3] as specified: one view per GPU and step, N timesteps frame-parallel")
     out = {
@@ -396,6 +562,7 @@ def main():
         "forward_split_colour": bool(use_pipeline and args.split_colour != "off"),
         "forward_ms": round(dt_fwd / n_fwd * 1e3, 4),
         "raster_ms": round(sum(v["ms"] for v in stages.values()), 4),
+        "live_gaussians": int(round(P_live)),
         "stages": stages,
         "stages_note": "per view, HIP events on the launch stream, from an untimed SINGLE-stream pass of %d steps (kernel "
                        "time, not queueing time behind the other stream); mean num_rendered of that pass %d; the dominant "
@@ -403,6 +570,15 @@ def main():
                            n_stage_steps, int(round(R_stage)), dom),
         "roofline": roofline,
     }
+    out["rccl_ranks"] = world
+    out["backend"] = backend if backend else "none (single process)"
+    if raster:
+        out["raster_images_s"] = raster["images_s"]
+        out["raster"] = raster
+    if dropin:
+        out["dropin_images_s"] = dropin["images_s"]
+        out["dropin_forward_ms"] = dropin["forward_ms"]
+        out["dropin"] = dropin
     if world == 1 and args.cpu_samples > 0:
         out["cpu_baseline"] = cpu_baseline(scene, args.cpu_samples)
     print(json.dumps(out))

@@ -253,6 +253,13 @@ int fdgs_debug_activations(int32_t P, const float* opacity_raw, const float* sca
  * The verdict must never be 0 where the brute force says 1. */
 int fdgs_debug_block_reaches(int32_t n, const float* tuples, uint8_t* out, void* stream);
 
+/* Measurement aid: a one-wave kernel on `stream` that records, into out5 (DEVICE memory, 5 x uint64), the constant-rate wall
+ * clock (s_memrealtime) and the shader-clock counter (s_memtime) at its start and again span_ms later, plus the wall clock's
+ * rate in kHz: { wall0, shader0, wall1, shader1, wall_khz }.  (shader1 - shader0) / (wall1 - wall0) * wall_khz = the shader
+ * clock in kHz the chip sustained over the interval, under whatever the caller's other streams were running (bench.py:
+ * valu_issue_frac at the MEASURED clock).  span_ms in (0, 2000]. */
+int fdgs_debug_clock_sample(uint64_t* out5, double span_ms, void* stream);
+
 /* Test hook: lists longer than `lds_cap` entries take the global-scratch sort, tiles whose most crowded depth bucket
  * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (4096, 48).  Process-wide. */
 void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);

@@ -40,10 +40,39 @@ def test_bench_two_ranks_share_one_gpu(views, dense, gpu_device):
     assert d["replicas_identical"] is True   # both ranks hold bit-identical parameters after the steps
 
 
+def test_bench_launches_its_own_ranks(gpu_device):
+    """`python bench.py --gpus 2` as the driver calls it (no torch.distributed.run in front): bench.py re-executes itself
+    through torch.distributed.run on 127.0.0.1, one process per rank, and rank 0 prints the one JSON line."""
+    env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C2",
+           "--cpu-samples", "0", "--host-cost-steps", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["replicas_identical"] is True
+    assert d["config"]["global_batch"] == 8 and d["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus(gpu_device):
+    """Without the debug switch, asking for more GPUs than the node has must fail loudly (not hang, not share a device)."""
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDGS_BENCH_DEBUG_SHARE_GPU"):
+        env.pop(k, None)
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "GPU(s) visible" in (out.stderr + out.stdout)
+
+
 def _run_bench(nproc, views, extra=()):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--workload", "C2",
-              "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0"] + list(extra)
+              "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0", "--dropin-steps", "0"] + list(extra)
     if nproc == 1:
         cmd = [sys.executable] + common
     else:
