@@ -24,8 +24,20 @@ FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
 _fp = C.c_void_p  # all device pointers travel as void*
 
 
-class FdgsScene(C.Structure):
+FDGS_VERSION = 300  # include/fdgs.h; checked against fdgs_version() at import
+
+
+class _Sized(C.Structure):
+    """Every struct of the ABI starts with ``struct_size`` = sizeof(struct) (include/fdgs.h: the library rejects any other value);
+    filled in here so that the call sites keep passing the remaining fields positionally."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class FdgsScene(_Sized):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("P", C.c_int32), ("D", C.c_int32), ("D_t", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
         ("bg", _fp), ("means3D", _fp), ("shs", _fp), ("colors_precomp", _fp), ("flows", _fp), ("opacities", _fp),
         ("ts", _fp), ("scales", _fp), ("scales_t", _fp), ("rotations", _fp), ("rotations_r", _fp),
@@ -38,28 +50,28 @@ class FdgsScene(C.Structure):
     ]
 
 
-class FdgsForwardOut(C.Structure):
-    _fields_ = [("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
+class FdgsForwardOut(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
                 ("out_means3D", _fp), ("covs_com", _fp), ("split_colour", C.c_int32)]
 
 
-class FdgsBackwardIn(C.Structure):
-    _fields_ = [("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_alpha", _fp), ("dL_dout_flow", _fp),
+class FdgsBackwardIn(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_alpha", _fp), ("dL_dout_flow", _fp),
                 ("radii", _fp), ("out_means3D", _fp), ("geom_buffer", _fp), ("binning_buffer", _fp),
                 ("image_buffer", _fp), ("num_rendered", C.c_int32)]
 
 
-class FdgsBackwardOut(C.Structure):
-    _fields_ = [("dL_dmeans2D", _fp), ("dL_dcolors", _fp), ("dL_dopacity", _fp), ("dL_dmeans3D", _fp),
+class FdgsBackwardOut(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("dL_dmeans2D", _fp), ("dL_dcolors", _fp), ("dL_dopacity", _fp), ("dL_dmeans3D", _fp),
                 ("dL_dcov3D", _fp), ("dL_dsh", _fp), ("dL_dflows", _fp), ("dL_dts", _fp), ("dL_dscales", _fp),
                 ("dL_dscales_t", _fp), ("dL_drotations", _fp), ("dL_drotations_r", _fp), ("accumulate", C.c_int32),
                 ("grad_accum", _fp), ("grad_accum_clean", C.c_int32), ("sh_stage", _fp), ("stage_mask", C.c_int32)]
 
 
-class FdgsDebugView(C.Structure):
-    _fields_ = [("depths", _fp), ("records", _fp), ("cov3D", _fp), ("tiles_touched", _fp), ("clamped", _fp),
+class FdgsDebugView(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("depths", _fp), ("records", _fp), ("cov3D", _fp), ("tiles_touched", _fp), ("clamped", _fp),
                 ("point_list", _fp), ("ranges", _fp), ("n_contrib", _fp),
-                ("final_T", _fp)]
+                ("final_T", _fp), ("tile_order", _fp)]
 
 
 class FdgsAdamSegment(C.Structure):
@@ -71,7 +83,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
@@ -108,6 +120,8 @@ def _load():
     lib.fdgs_debug_block_reaches.restype = C.c_int
     lib.fdgs_debug_run_ahead_stats.argtypes = [C.POINTER(C.c_int64)]
     lib.fdgs_debug_run_ahead_stats.restype = None
+    lib.fdgs_set_run_ahead.argtypes = [C.c_int32]
+    lib.fdgs_set_run_ahead.restype = None
     lib.fdgs_debug_clock_sample.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     lib.fdgs_debug_clock_sample.restype = C.c_int
     lib.fdgs_sh_flush.argtypes = [C.c_int32] * 8 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -152,6 +166,9 @@ def _load():
     lib.fdgs_dist2_knn3.restype = C.c_int
     lib.fdgs_last_error.restype = C.c_char_p
     lib.fdgs_version.restype = C.c_int
+    if lib.fdgs_version() != FDGS_VERSION:
+        raise ImportError("%s is version %d, this binding was written for FDGS_VERSION %d (include/fdgs.h): rebuild the library "
+                          "(4d-gaussian-splatting_amd/csrc/build.sh)" % (LIB_PATH, lib.fdgs_version(), FDGS_VERSION))
     return lib
 
 

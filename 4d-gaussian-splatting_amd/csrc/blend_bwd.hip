@@ -139,7 +139,7 @@ namespace fdgs
 	template <bool AUX>
 	__global__ void __launch_bounds__(WAVE) blend_bwd_kernel(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
-		int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
+		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
 		const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
 		const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_masks,
 		const float* __restrict__ dL_dpix_flow,
@@ -153,7 +153,7 @@ namespace fdgs
 		// loop addresses the whole queue with ONE base register and immediate offsets
 		__shared__ float4 s_q[7][QP];
 
-		const BlockId blk = block_of(blockIdx.x, ntiles);
+		const BlockId blk = block_of(blockIdx.x, ntiles, tile_order);
 		if (blk.tile >= ntiles) return;
 		const int lane = threadIdx.x;
 		const int bx0 = (blk.tile % grid_x) * TILE_X + (blk.sub & 1) * BLK;
@@ -359,14 +359,14 @@ namespace fdgs
 	}
 
 	hipError_t launch_blend_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
-	                            const float* records, const uint32_t* point_list, const uint32_t* ranges,
+	                            const float* records, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
 	                            const float* final_T, const uint32_t* n_contrib, hipStream_t stream)
 	{
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
 		const int ntiles = gx * gy;
 #define LAUNCH_BWD(AUX) hipLaunchKernelGGL((blend_bwd_kernel<AUX>), dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream, \
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records), \
-		                   s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib, \
+		                   tile_order, s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib, \
 		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow, out.grad_accum)
 		if (s.P >= (1 << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets into the 64-byte accumulator records
 		if (in.dL_dout_depth || in.dL_dout_alpha || in.dL_dout_flow) LAUNCH_BWD(true);

@@ -20,7 +20,7 @@ namespace fdgs
 
 	__global__ void __launch_bounds__(WAVE) blend_fwd_kernel(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
-		int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
+		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
 		float* __restrict__ out_color, float* __restrict__ out_flow, float* __restrict__ out_depth, float* __restrict__ out_T,
 		float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 	{
@@ -33,7 +33,7 @@ namespace fdgs
 		// other rows, so the loop addresses the whole queue with one base register and immediate offsets
 		__shared__ float4 s_q[7][QP];
 
-		const BlockId blk = block_of(blockIdx.x, ntiles);
+		const BlockId blk = block_of(blockIdx.x, ntiles, tile_order);
 		if (blk.tile >= ntiles) return;
 		const int lane = threadIdx.x;
 		const int bx0 = (blk.tile % grid_x) * TILE_X + (blk.sub & 1) * BLK;
@@ -155,7 +155,7 @@ namespace fdgs
 	}
 
 	hipError_t launch_blend_fwd(const fdgs_scene& s, const fdgs_forward_out& out, const float* records,
-	                            const uint32_t* point_list, const uint32_t* ranges,
+	                            const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
 	                            float* final_T, uint32_t* n_contrib, hipStream_t stream)
 	{
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
@@ -163,7 +163,7 @@ namespace fdgs
 		if (s.P >= (1 << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets into the 48-byte records
 		hipLaunchKernelGGL(blend_fwd_kernel, dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream,
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records),
-		                   s.W, s.H, gx, ntiles, s.bg,
+		                   tile_order, s.W, s.H, gx, ntiles, s.bg,
 		                   out.out_color, out.out_flow, out.out_depth, out.out_T, final_T, n_contrib);
 		return hipGetLastError();
 	}

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "fdgs_common.h"
 
@@ -123,9 +124,19 @@ extern "C" const char* fdgs_stage_name(int stage) { return (stage >= 0 && stage 
 		if (debug) HIP_TRY(hipStreamSynchronize(stream), what);                                     \
 	} while (0)
 
+// every struct of the ABI starts with its own size as the caller's header defined it: a caller built against another fdgs.h
+// is turned away here instead of the library reading past the end of a shorter struct
+#define CHECK_STRUCT(ptr, type)                                                                                           \
+	do {                                                                                                                  \
+		if ((ptr)->struct_size != (uint32_t)sizeof(type))                                                                 \
+			return fail(FDGS_ERR_INVALID_ARG, #type ".struct_size is %u, this library (FDGS_VERSION %d) expects %zu: built against another fdgs.h?", \
+			            (unsigned)(ptr)->struct_size, FDGS_VERSION, sizeof(type));                                        \
+	} while (0)
+
 static int check_scene(const fdgs_scene* s)
 {
 	if (!s) return fail(FDGS_ERR_INVALID_ARG, "scene is NULL");
+	CHECK_STRUCT(s, fdgs_scene);
 	if (s->P < 0 || s->W <= 0 || s->H <= 0) return fail(FDGS_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", s->P, s->W, s->H);
 	if (div_up(s->W, TILE_X) > 65535 || div_up(s->H, TILE_Y) > 65535) return fail(FDGS_ERR_INVALID_ARG, "image too large for 16-bit tile rectangles");
 	if (s->P == 0) return FDGS_OK;
@@ -165,6 +176,10 @@ extern "C" int fdgs_version(void) { return FDGS_VERSION; }
 // how the forward calls of this process went: [0] everything enqueued ahead of num_rendered and kept, [1] ahead but sorted
 // again (longer lists than guessed), [2] exact sizes (first call of a thread, debug mode, or more instances than guessed)
 static std::atomic<long long> g_run_ahead[3];
+static std::atomic<bool> g_run_ahead_enabled{true};
+constexpr int FDGS_MAX_DEVICES = 64;
+constexpr int FDGS_GUESS_SLOTS = 8;
+extern "C" void fdgs_set_run_ahead(int32_t enable) { g_run_ahead_enabled.store(enable != 0); }
 extern "C" void fdgs_debug_run_ahead_stats(int64_t* counts3)
 {
 	for (int k = 0; k < 3; k++) counts3[k] = (int64_t)g_run_ahead[k].load();
@@ -174,9 +189,11 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
                                       fdgs_alloc_fn alloc, void* alloc_user, void* stream_v, int32_t* num_rendered)
 {
 	g_err[0] = 0;
+	if (!scene || !out || !alloc || !num_rendered) return fail(FDGS_ERR_INVALID_ARG, "scene / out / alloc / num_rendered must not be NULL");
+	CHECK_STRUCT(scene, fdgs_scene);
+	CHECK_STRUCT(out, fdgs_forward_out);
 	int rc = check_scene(scene);
 	if (rc != FDGS_OK) return rc;
-	if (!out || !alloc || !num_rendered) return fail(FDGS_ERR_INVALID_ARG, "out / alloc / num_rendered must not be NULL");
 	const fdgs_scene& s = *scene;
 	hipStream_t stream = (hipStream_t)stream_v;
 	const bool debug = s.debug != 0;
@@ -197,20 +214,29 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 
 	uint32_t* counters = (uint32_t*)(img + IL.tile_counters);
 	uint32_t* ctl = (uint32_t*)(img + IL.bin_ctl);
+	// tile order of the blend kernels (written by the scan); FDGS_TILE_ORDER=0 in the environment: index order (A/B timing)
+	static const bool use_order = []() { const char* e = getenv("FDGS_TILE_ORDER"); return !(e && e[0] == '0'); }();
+	uint32_t* tile_order = use_order ? (uint32_t*)(img + IL.tile_order) : nullptr;
 	const float* records = (const float*)(geom + GL.records);
 	if (P == 0)
 	{
 		// nothing to bin; the blend kernel still writes background colour / T = 1 everywhere
 		if (!alloc(alloc_user, FDGS_BUF_BINNING, bin_layout(0, false).total)) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
 		STAGE(FDGS_STAGE_TILE_SORT, hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
-		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, nullptr, ranges, final_T, n_contrib, stream), "blend_fwd");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, nullptr, ranges, nullptr, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
 	}
 
+	// Per-thread forward state, keyed by the device the call runs on (a host thread may drive several GPUs): the second stream
+	// and its events (split_colour), the pinned mailbox, the run-ahead guesses.
+	int dev_id = 0;
+	HIP_TRY(hipGetDevice(&dev_id), "hipGetDevice");
+	if (dev_id < 0 || dev_id >= FDGS_MAX_DEVICES) return fail(FDGS_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev_id, FDGS_MAX_DEVICES);
 	// split_colour: the SH colours are only needed by the blend -- they are evaluated on a second stream of this thread's while
 	// the binning runs on the caller's (event after the geometry launch, event back before the blend)
 	struct Aux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-	static thread_local Aux aux;
+	static thread_local Aux aux_of[FDGS_MAX_DEVICES];
+	Aux& aux = aux_of[dev_id];
 	const bool split = out->split_colour != 0 && s.shs != nullptr && !debug;
 	if (split)
 	{
@@ -232,6 +258,13 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	else
 		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, 0, stream), "preprocess_fwd");
 	bool joined = !split;   // the blend must not start before the colours are there
+	// whichever way this call returns from here on: work on the second stream writes into this call's geometry buffer, so the
+	// caller's stream waits for it (the buffer may be released in stream order right after an error return)
+	struct JoinGuard
+	{
+		hipStream_t stream; Aux& aux; bool& joined;
+		~JoinGuard() { if (!joined && aux.join) (void)hipStreamWaitEvent(stream, aux.join, 0); }
+	} join_guard{ stream, aux, joined };
 	const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
 	const float* depths = (const float*)(geom + GL.depths);
 	STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
@@ -240,7 +273,8 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	// rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the ticket does not show up
 	// (a failed launch), the stream is synchronised and the error reported.
 	struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t ticket = 0; };
-	static thread_local Mailbox box;
+	static thread_local Mailbox box_of[FDGS_MAX_DEVICES];
+	Mailbox& box = box_of[dev_id];
 	if (!box.host)
 	{
 		void* h = nullptr;
@@ -251,7 +285,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
 	}
 	const uint32_t ticket = ++box.ticket ? box.ticket : ++box.ticket;   // never 0
-	STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev, ticket, stream), "tile scan");
+	STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev, ticket, tile_order, stream), "tile scan");
 
 	// Run-ahead.  The reference stops here until num_rendered has come back and sizes the binning buffers with it
 	// (rasterizer_impl.cu:302-306): the device idles for a host round trip in the middle of the forward.  Views follow each
@@ -260,10 +294,23 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	// everything alone when it does not fit (the sort then reports every tile empty, so the blend behind it reads nothing).
 	// The host picks up the mailbox afterwards (written long before) and, when the guess was too small, starts over from
 	// the scatter pass with exact sizes.
-	struct RunAhead { long long capacity = 0; int longest = 0; };
-	static thread_local RunAhead guess;
+	// the guess is kept per (device, image size, P): a thread that alternates between scenes or resolutions keeps one per
+	// configuration (a few slots, replaced round-robin)
+	struct RunAhead { int dev = -1, W = 0, H = 0, P = 0; long long capacity = 0; int longest = 0; };
+	static thread_local RunAhead guesses[FDGS_GUESS_SLOTS];
+	static thread_local int guess_next = 0;
+	RunAhead* gp = nullptr;
+	for (auto& g : guesses) if (g.dev == dev_id && g.W == W && g.H == H && g.P == P) gp = &g;
+	if (!gp)
+	{
+		gp = &guesses[guess_next];
+		guess_next = (guess_next + 1) % FDGS_GUESS_SLOTS;
+		*gp = RunAhead();
+		gp->dev = dev_id; gp->W = W; gp->H = H; gp->P = P;
+	}
+	RunAhead& guess = *gp;
 	const int lds_cap = tile_sort_lds_cap();
-	const bool ahead = guess.capacity > 0 && !debug;
+	const bool ahead = guess.capacity > 0 && !debug && g_run_ahead_enabled.load(std::memory_order_relaxed);
 	const long long ahead_cap = guess.capacity;
 	const int ahead_longest = guess.longest;
 	char* bin = nullptr;
@@ -278,7 +325,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, sort_longest, pairs, point_list, ranges,
 		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, stream), "tile sort");
 		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
-		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
 	};
 	if (ahead)
@@ -332,7 +379,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");   // stream-ordered: after the sort, whether it was launched or not
 		HIP_TRY(sorted, "tile sort");
 		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
-		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, final_T, n_contrib, stream), "blend_fwd");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
 	}
 	// first call of this thread, debug mode, or more instances than guessed (nothing was scattered): exact sizes
@@ -348,9 +395,12 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
                                        const fdgs_backward_out* out, void* stream_v)
 {
 	g_err[0] = 0;
+	if (!scene || !in || !out) return fail(FDGS_ERR_INVALID_ARG, "scene / in / out must not be NULL");
+	CHECK_STRUCT(scene, fdgs_scene);
+	CHECK_STRUCT(in, fdgs_backward_in);
+	CHECK_STRUCT(out, fdgs_backward_out);
 	int rc = check_scene(scene);
 	if (rc != FDGS_OK) return rc;
-	if (!in || !out) return fail(FDGS_ERR_INVALID_ARG, "in / out must not be NULL");
 	const fdgs_scene& s = *scene;
 	hipStream_t stream = (hipStream_t)stream_v;
 	const bool debug = s.debug != 0;
@@ -377,6 +427,8 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	const char* bin = (const char*)in->binning_buffer;
 	const uint32_t* point_list = (const uint32_t*)(bin + BL.point_list);
 
+	// the forward's tile order (left in the image buffer by the scan); not there for P == 0 (returned above) or with FDGS_TILE_ORDER=0
+	static const bool bwd_order = []() { const char* e = getenv("FDGS_TILE_ORDER"); return !(e && e[0] == '0'); }();
 	const int stages = (out->stage_mask & 3) ? (out->stage_mask & 3) : 3;
 	if (stages & 1)
 	{
@@ -385,7 +437,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 			STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->grad_accum, 0, (size_t)P * GRAD_ACC_WORDS * 4, stream), "memset");
 		if (R > 0)
 			STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
-			                       (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
+			                       bwd_order ? (const uint32_t*)(img + IL.tile_order) : nullptr, (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
 		STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
 	}
 	if (stages & 2)
@@ -472,6 +524,7 @@ extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
 {
 	g_err[0] = 0;
 	if (!v || !geom_v || !img_v) return fail(FDGS_ERR_INVALID_ARG, "NULL argument");
+	CHECK_STRUCT(v, fdgs_debug_view);
 	const GeomLayout GL = geom_layout(P);
 	const ImageLayout IL = image_layout(W, H);
 	const BinLayout BL = bin_layout(R, false);
@@ -487,5 +540,6 @@ extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
 	v->ranges = (const uint32_t*)(img + IL.ranges);
 	v->n_contrib = (const uint32_t*)(img + IL.n_contrib);
 	v->final_T = (const float*)(img + IL.final_T);
+	v->tile_order = (const uint32_t*)(img + IL.tile_order);
 	return FDGS_OK;
 }

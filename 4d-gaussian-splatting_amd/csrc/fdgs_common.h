@@ -58,6 +58,8 @@ namespace fdgs
 		size_t final_T, n_contrib, ranges;
 		size_t tile_counters;   // [T] instance counts -> exclusive starts -> ends (count / scan / scatter passes)
 		size_t bin_ctl;         // { R, longest tile list } written by the scan, read back by the host
+		size_t tile_order;      // [T] the order in which the blend kernels take the tiles (longest lists first inside every XCD's
+		                        // band of tiles), written by the scan kernel; [T] more words of scratch behind it
 		size_t total;
 	};
 	static inline ImageLayout image_layout(int W, int H)
@@ -71,6 +73,7 @@ namespace fdgs
 		L.ranges = o; o = align_up(o + t * 8);
 		L.tile_counters = o; o = align_up(o + bin_counter_words((int)t) * 4);
 		L.bin_ctl = o; o = align_up(o + 16);
+		L.tile_order = o; o = align_up(o + 2 * t * 4);
 		L.total = o;
 		return L;
 	}
@@ -109,7 +112,8 @@ namespace fdgs
 	// scatter its end.  ctl[0] = R, ctl[1] = longest tile list.
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream);
 	// host_box (optional): device pointer of a pinned host mailbox {R, longest, ticket} the kernel writes directly
-	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, hipStream_t stream);
+	// tile_order (optional, 2 T words): see ImageLayout
+	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, uint32_t* tile_order, hipStream_t stream);
 	// scatter / sort may be launched before the host knows num_rendered: they compare ctl[0] with `capacity` (the instances
 	// pairs / point_list hold) and leave everything alone -- the sort reports every tile empty -- when it does not fit
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
@@ -119,12 +123,13 @@ namespace fdgs
 	int tile_sort_lds_cap();                                   // lists longer than this need the global scratch
 	void tile_sort_debug_limits(int lds_cap, int rank_max);    // test hook (fdgs_debug_tile_sort_limits); <= 0 restores the default
 
+	// tile_order: NULL = tiles in index order
 	hipError_t launch_blend_fwd(const fdgs_scene& s, const fdgs_forward_out& out, const float* records,
-	                            const uint32_t* point_list, const uint32_t* ranges,
+	                            const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
 	                            float* final_T, uint32_t* n_contrib, hipStream_t stream);
 
 	hipError_t launch_blend_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
-	                            const float* records, const uint32_t* point_list, const uint32_t* ranges,
+	                            const float* records, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
 	                            const float* final_T, const uint32_t* n_contrib, hipStream_t stream);
 
 	// SH / 4D-SH backward (coalesced); must run after the blend backward and before launch_preprocess_bwd

@@ -177,12 +177,16 @@ namespace fdgs
 	// exclusive scan of the tile counters by ONE workgroup; ctl[0] = R, ctl[1] = longest tile list
 	// ------------------------------------------------------------------------------------------------
 	constexpr int SCAN_T = 1024;
+	constexpr int ORDER_BUCKETS = 64;   // list lengths are ranked in 64 linear classes of the longest list
 	__global__ void __launch_bounds__(SCAN_T) tile_scan_kernel(uint32_t* __restrict__ counters, int T, int per_thread /* multiple of 4 */,
-	                                                           uint32_t* __restrict__ ctl, uint32_t* __restrict__ host_box, uint32_t ticket)
+	                                                           uint32_t* __restrict__ ctl, uint32_t* __restrict__ host_box, uint32_t ticket,
+	                                                           uint32_t* __restrict__ order /* [2 T] or NULL */, int band /* tiles per XCD */)
 	{
 		__shared__ uint32_t s_w[SCAN_T / WAVE], s_m[SCAN_T / WAVE];
+		__shared__ uint32_t s_cls[8 * ORDER_BUCKETS];   // tiles per (XCD band, length class) -> start of the class inside its band
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const int first = threadIdx.x * per_thread;
+		if (threadIdx.x < 8 * ORDER_BUCKETS) s_cls[threadIdx.x] = 0u;
 		// the counter array is padded to a multiple of 4 words (zeros), so the uint4 accesses stay inside it
 		uint32_t sum = 0, m = 0;
 		for (int i = 0; i < per_thread; i += 4)
@@ -210,7 +214,14 @@ namespace fdgs
 			gtot += s_w[w2];
 			gmax = max(gmax, s_m[w2]);
 		}
+		// Order of the tiles for the blend kernels (blend_common.h, block_of): inside every XCD's band of `band` consecutive tiles
+		// the longest lists go first -- a counting sort over ORDER_BUCKETS length classes (class 0 = the longest); the rank of a
+		// tile inside its class is whatever the LDS atomic hands out (the order only schedules work, no result depends on it).
+		const float cls_scale = (float)ORDER_BUCKETS / ((float)gmax + 1.0f);
+		uint32_t* const order_tmp = order ? order + T : nullptr;
 		uint32_t run = base + incl - sum;
+		const int band0 = first / band;      // the band of this thread's first tile; its tiles are consecutive
+		int bnd = band0, bnd_end = (band0 + 1) * band;
 		for (int i = 0; i < per_thread; i += 4)
 		{
 			if (first + i >= T) break;
@@ -222,6 +233,50 @@ namespace fdgs
 			o.z = run; run += v.z;
 			o.w = run; run += v.w;
 			*p = o;
+			if (order)
+			{
+				const uint32_t c4[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for (int c = 0; c < 4; c++)
+				{
+					const int t = first + i + c;
+					while (t >= bnd_end) { bnd++; bnd_end += band; }
+					if (t < T)
+					{
+						const uint32_t cls = (uint32_t)(ORDER_BUCKETS - 1) - min((uint32_t)(ORDER_BUCKETS - 1), (uint32_t)((float)c4[c] * cls_scale));
+						const uint32_t rank = atomicAdd(&s_cls[bnd * ORDER_BUCKETS + cls], 1u);
+						order_tmp[t] = (cls << 24) | rank;   // read back below by this same thread
+					}
+				}
+			}
+		}
+		if (order)
+		{
+			__syncthreads();
+			if (threadIdx.x < 8 * ORDER_BUCKETS)
+			{
+				// exclusive scan of the class sizes of one band by one wave (lane = class)
+				const uint32_t n = s_cls[threadIdx.x];
+				uint32_t inc = n;
+#pragma unroll
+				for (int o = 1; o < WAVE; o <<= 1)
+				{
+					const uint32_t t = __shfl_up(inc, o);
+					if (lane >= o) inc += t;
+				}
+				s_cls[threadIdx.x] = inc - n;
+			}
+			__syncthreads();
+			bnd = band0; bnd_end = (band0 + 1) * band;
+			for (int i = 0; i < per_thread; i++)
+			{
+				const int t = first + i;
+				if (t >= T) break;
+				while (t >= bnd_end) { bnd++; bnd_end += band; }
+				const uint32_t cr = order_tmp[t];
+				const int b = bnd;
+				order[b * band + s_cls[b * ORDER_BUCKETS + (cr >> 24)] + (cr & 0xFFFFFFu)] = (uint32_t)t;
+			}
 		}
 		if (threadIdx.x == 0)
 		{
@@ -541,9 +596,18 @@ namespace fdgs
 		uint2* p2 = reinterpret_cast<uint2*>(pairs);
 		if (T <= BIN_LDS_MAX_TILES)
 		{
-			static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_bin_lds_kernel<SCATTER>),
-			                                                   hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4);
-			if (attr != hipSuccess) return attr;
+			// the attribute belongs to the (kernel, device) pair: set once per device this process launches on
+			static std::atomic<unsigned long long> attr_done{0};   // bit d: set on device d
+			int dev = 0;
+			hipError_t e = hipGetDevice(&dev);
+			if (e != hipSuccess) return e;
+			if (dev >= 64 || !((attr_done.load(std::memory_order_acquire) >> dev) & 1ull))
+			{
+				e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_bin_lds_kernel<SCATTER>),
+				                        hipFuncAttributeMaxDynamicSharedMemorySize, BIN_LDS_MAX_TILES * 4);
+				if (e != hipSuccess) return e;
+				if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
+			}
 			const int rounds = bin_rounds(T);
 			hipLaunchKernelGGL(tile_bin_lds_kernel<SCATTER>, dim3(div_up(P, rounds * BIN_T)), dim3(BIN_T), (size_t)T * 4, stream, r4, depths, P,
 			                   grid_x, T, rounds, counters, p2, ctl, capacity);
@@ -559,10 +623,12 @@ namespace fdgs
 		return launch_tile_bin<false>(rect, nullptr, P, grid_x, T, counters, nullptr, nullptr, 0u, stream);
 	}
 
-	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, hipStream_t stream)
+	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, uint32_t* tile_order, hipStream_t stream)
 	{
 		const int per_thread = div_up(div_up(T, SCAN_T), 4) * 4;
-		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl, host_box, ticket);
+		const int band = div_up(T, 8);   // = the tiles per XCD of blend_common.h, block_of (NUM_XCDS)
+		if (band >= (1 << 24)) tile_order = nullptr;
+		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl, host_box, ticket, tile_order, band);
 		return hipGetLastError();
 	}
 

@@ -30,10 +30,17 @@
  *  - gradients are bug-compatible with the reference backward (SURVEY.md
  *    Appendix A, Q1-Q13).
  *
- * All functions are re-entrant and keep no global state besides a thread-local
- * last-error string.  All work is enqueued on `stream`; fdgs_rasterize_forward
- * waits for the device once (for num_rendered, as the reference does at
- * rasterizer_impl.cu:302): it spins on a pinned mailbox the tile-scan kernel writes.
+ * Threading contract.  All work is enqueued on the caller's `stream`; fdgs_rasterize_forward waits for the device once
+ * (for num_rendered, as the reference does at rasterizer_impl.cu:302): it spins on a pinned mailbox the tile-scan kernel
+ * writes.  The library keeps, PER HOST THREAD AND DEVICE: the last-error string, that pinned mailbox, a second stream with
+ * two events (fdgs_forward_out.split_colour) and the run-ahead guesses (sizes of the thread's previous forward calls per
+ * (device, W, H, P)).  Consequence: any number of host threads may call concurrently (each with its own stream), and one
+ * thread may drive several devices (hipSetDevice before the call); within ONE thread a forward call has returned before the
+ * next one starts, so there is never more than one forward of a thread in flight on the host side.  Process-wide state:
+ * the profiling accumulators (fdgs_profile_*, mutex-guarded), the test hooks fdgs_debug_tile_sort_limits /
+ * fdgs_set_run_ahead, and the counters of fdgs_debug_run_ahead_stats.
+ * Limits: P < 2^26 Gaussians per call (the blend kernels address the 48- / 64-byte per-Gaussian records with 32-bit byte
+ * offsets; FDGS_ERR_HIP "invalid value" beyond), num_rendered < 2^31, image sides below 16 * 65535 pixels.
  */
 #ifndef FDGS_H
 #define FDGS_H
@@ -44,7 +51,10 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 100 /* 0.1.0 */
+#define FDGS_VERSION 300 /* 0.3.0.  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+                            (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
+                            FDGS_VERSION: a binding built against another revision of this header is turned away instead of
+                            having the library read past the end of a shorter struct. */
 
 /* error codes */
 #define FDGS_OK 0
@@ -72,6 +82,7 @@ typedef void* (*fdgs_alloc_fn)(void* user, int which, size_t bytes);
  * plus the per-call tensors). */
 typedef struct fdgs_scene
 {
+	uint32_t struct_size; /* sizeof(fdgs_scene)                                    */
 	int32_t P;            /* number of Gaussians                                   */
 	int32_t D, D_t, M;    /* active SH degree, active time degree, SH coeffs/pt    */
 	int32_t W, H;         /* image_width, image_height                             */
@@ -113,6 +124,7 @@ typedef struct fdgs_scene
 /* Forward outputs; every array is fully written by the call (no pre-zeroing needed). */
 typedef struct fdgs_forward_out
 {
+	uint32_t struct_size; /* sizeof(fdgs_forward_out)                              */
 	float* out_color;     /* [3,H,W]                                               */
 	float* out_flow;      /* [2,H,W]                                               */
 	float* out_depth;     /* [1,H,W]                                               */
@@ -132,6 +144,7 @@ typedef struct fdgs_forward_out
    backward blend runs its colour-only variant. */
 typedef struct fdgs_backward_in
 {
+	uint32_t struct_size;        /* sizeof(fdgs_backward_in)                       */
 	const float* dL_dout_color;  /* [3,H,W]                                        */
 	const float* dL_dout_depth;  /* [1,H,W]                                        */
 	const float* dL_dout_alpha;  /* [1,H,W]  gradient w.r.t. alpha = 1 - T         */
@@ -149,6 +162,7 @@ typedef struct fdgs_backward_in
  * the corresponding input is absent. */
 typedef struct fdgs_backward_out
 {
+	uint32_t struct_size;   /* sizeof(fdgs_backward_out)                           */
 	float* dL_dmeans2D;     /* [P,3]  (x,y in NDC-scaled units, z = depth carrier, Q10) */
 	float* dL_dcolors;      /* [P,3]                                               */
 	float* dL_dopacity;     /* [P]                                                 */
@@ -192,6 +206,11 @@ int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                            fdgs_alloc_fn alloc, void* alloc_user, void* stream,
                            int32_t* num_rendered);
 
+/* 1 (default): the forward enqueues scatter / sort / blend before num_rendered is back, with a binning buffer sized from the
+ * calling thread's previous call; 0: it always waits and asks the allocator for exactly fdgs_binning_bytes(num_rendered)
+ * (+ the long-list scratch), as the reference does.  Process-wide. */
+void fdgs_set_run_ahead(int32_t enable);
+
 /* Introspection for tests: how the forward calls of this process went -- counts3[0] scatter / sort / blend enqueued before
  * num_rendered was back and kept, [1] enqueued ahead but sorted again (longer tile lists than the previous call suggested),
  * [2] sized exactly after the wait (first call of a thread, debug mode, more instances than the previous call suggested). */
@@ -213,8 +232,13 @@ int fdgs_sh_flush(int32_t P, int32_t D, int32_t D_t, int32_t M, int32_t gaussian
 int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                       const float* projmatrix, uint8_t* present, void* stream);
 
-/* Sizes of the opaque scratch buffers (what the allocator will be asked for; the binning buffer grows by 8 bytes per
- * instance in the rare case that a single tile's list is longer than the LDS sort takes, 4096 entries). */
+/* Sizes of the opaque scratch buffers.  Geometry and image: exactly what the allocator is asked for.  Binning: the allocator
+ * is asked for fdgs_binning_bytes(n) with n = num_rendered when the forward sizes the buffer after the wait (first call of a
+ * thread for a (device, W, H, P), debug mode, fdgs_set_run_ahead(0)), and with n = 1.25 R' + 4096 <= 2^31 - 1 when it runs
+ * ahead (R' = num_rendered of the thread's previous call for the same (device, W, H, P)); a second request in the same call
+ * follows if that was too small.  Either request grows by 8 bytes per instance (of n) in the rare case that a single tile's
+ * list is longer than the LDS sort takes (4096 entries).  A caller that pre-sizes a binning arena either uses that bound
+ * or switches the run-ahead off. */
 size_t fdgs_geometry_bytes(int32_t P);
 size_t fdgs_image_bytes(int32_t W, int32_t H);
 size_t fdgs_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
@@ -223,6 +247,7 @@ size_t fdgs_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
  * finished forward call.  Arrays are indexed as documented in DESIGN.md. */
 typedef struct fdgs_debug_view
 {
+	uint32_t struct_size;          /* sizeof(fdgs_debug_view)                      */
 	const float* depths;           /* [P]   view-space z (0 where culled)          */
 	const float* records;          /* [P,12] packed blend record: x,y,conic(3),opacity,r,g,b,depth,flow(2) */
 	const float* cov3D;            /* [P,6]                                        */
@@ -232,6 +257,9 @@ typedef struct fdgs_debug_view
 	const uint32_t* ranges;        /* [T,2]                                        */
 	const uint32_t* n_contrib;     /* [H*W]                                        */
 	const float* final_T;          /* [H*W]                                        */
+	const uint32_t* tile_order;    /* [T]   the order in which the blend kernels take the tiles: a permutation of every XCD's band
+	                                  of ceil(T / 8) consecutive tiles, longest lists first (64 length classes); written by the
+	                                  tile scan, so undefined for P == 0 */
 } fdgs_debug_view;
 int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
@@ -261,7 +289,7 @@ int fdgs_debug_block_reaches(int32_t n, const float* tuples, uint8_t* out, void*
 int fdgs_debug_clock_sample(uint64_t* out5, double span_ms, void* stream);
 
 /* Test hook: lists longer than `lds_cap` entries take the global-scratch sort, tiles whose most crowded depth bucket
- * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (4096, 48).  Process-wide. */
+ * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (4096, 96).  Process-wide. */
 void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);
 
 /* Optional per-stage timing with HIP events recorded on the caller's stream (so the

@@ -24,7 +24,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_capi.lib, n), "libfdgs.so does not export %s" % n
         assert n in _capi.EXPORTED or n in ("fdgs_alloc_fn",), "binding list misses %s" % n
-    assert _capi.lib.fdgs_version() >= 100
+    assert _capi.lib.fdgs_version() == _capi.FDGS_VERSION == 300
+    with open(os.path.join(ROOT, "include", "fdgs.h")) as f:
+        assert re.search(r"#define FDGS_VERSION (\d+)", f.read()).group(1) == str(_capi.FDGS_VERSION)
 
 
 def test_scratch_sizes_are_monotone_and_aligned():
@@ -52,6 +54,29 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     assert rc == 1 and "must not be NULL" in _capi.last_error()
     assert _capi.lib.fdgs_mark_visible(-1, None, None, None, None, None) == 1
     assert _capi.lib.fdgs_profile_read(99, None, None) == 1
+
+
+def test_structs_carry_their_size_and_a_short_struct_is_rejected():
+    """Every ABI struct starts with struct_size; a caller built against another header (here: a size that is off by one field) gets
+    FDGS_ERR_INVALID_ARG instead of the library reading past the end of its struct."""
+    from fdgs import _capi
+    for cls in (_capi.FdgsScene, _capi.FdgsForwardOut, _capi.FdgsBackwardIn, _capi.FdgsBackwardOut, _capi.FdgsDebugView):
+        assert cls().struct_size == C.sizeof(cls) and cls._fields_[0][0] == "struct_size"
+    scene, out = _capi.FdgsScene(), _capi.FdgsForwardOut()
+    scene.P, scene.W, scene.H = 10, 16, 16
+    R = C.c_int32(0)
+    cb = _capi.ALLOC_FN(lambda u, w, n: None)
+    scene.struct_size -= 4
+    assert _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), cb, None, None, C.byref(R)) == 1
+    assert "struct_size" in _capi.last_error() and "fdgs_scene" in _capi.last_error()
+    scene.struct_size += 4
+    out.struct_size = 0
+    assert _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), cb, None, None, C.byref(R)) == 1
+    assert "fdgs_forward_out" in _capi.last_error()
+    bi, bo = _capi.FdgsBackwardIn(), _capi.FdgsBackwardOut()
+    bo.struct_size += 8
+    assert _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bi), C.byref(bo), None) == 1
+    assert "fdgs_backward_out" in _capi.last_error()
 
 
 def _settings(**kw):

@@ -428,6 +428,30 @@ def test_split_colour_forward_is_bit_identical(cfg, gpu_device):
     assert (outs[0]["rgb"] != 0).any() and outs[0]["R"] > 0
 
 
+@pytest.mark.parametrize("cfg", [SC("o1", 40000, 640, 480, 0, 0, 0.02, 1.0, True, 4, True), SC("o2", 3000, 100, 36, 0, 0, 0.03, 1.0, True, 4, True),
+                                 SC("o3", 3000, 3104, 3104, 0, 0, 0.02, 1.0, True, 4, True)], ids=["1200-tiles", "21-tiles", "37636-tiles"])
+def test_tile_order_is_a_banded_longest_first_permutation(cfg, gpu_device):
+    """The order in which the blend kernels take the tiles (fdgs_debug_view.tile_order, written by the tile scan): a permutation
+    that keeps every tile inside its XCD's band of ceil(T / 8) consecutive tiles and puts longer lists first (64 length classes of
+    the longest list: monotone up to one class width)."""
+    scene = synth.make_scene(cfg, seed=21)
+    hip, _ = run_hip(scene, gpu_device, None)
+    order, rg = hip["tile_order"], hip["ranges"].astype(np.int64)
+    T = rg.shape[0]
+    assert order.shape == (T,) and np.array_equal(np.sort(order), np.arange(T))
+    n = rg[:, 1] - rg[:, 0]
+    band = -(-T // 8)
+    width = (int(n.max()) + 1) / 64.0 + 1.0
+    for b in range(8):
+        sl = order[b * band:min((b + 1) * band, T)]
+        if sl.size == 0:
+            continue
+        assert sl.min() >= b * band and sl.max() < min((b + 1) * band, T), "band %d leaks" % b
+        ln = n[sl]
+        assert (ln[:-1] + width >= ln[1:]).all(), "band %d is not longest-first" % b
+    assert n.max() > 0
+
+
 def test_binning_many_tiles_direct_path(gpu_device):
     """More tiles than an LDS histogram holds (> 36 864): count / scatter fall back to one global atomic per instance."""
     scene = synth.make_scene(SC("v", 3000, 3104, 3104, 0, 0, 0.02, 1.0, True, 4, True), seed=14)

@@ -70,6 +70,7 @@ def collect_forward(res, P, W, H):
         "ranges": _view(img, v.ranges, ntiles * 2, torch.int32).reshape(ntiles, 2).cpu().numpy().astype(np.uint32),
         "n_contrib": _view(img, v.n_contrib, W * H, torch.int32).reshape(H, W).cpu().numpy().astype(np.uint32),
         "final_T": _view(img, v.final_T, W * H, torch.float32).reshape(H, W).cpu().numpy(),
+        "tile_order": _view(img, v.tile_order, ntiles, torch.int32).cpu().numpy().astype(np.int64),
         "means2D": rec[:, 0:2].copy(),
         "conic_opacity": np.concatenate([rec[:, 2:5], rec[:, 5:6]], axis=1),
         "rgb": rec[:, 6:9].copy(), "rec_depth": rec[:, 9].copy(), "rec_flow": rec[:, 10:12].copy(),
