@@ -321,7 +321,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
 		uint32_t* pairs = (uint32_t*)(bin + BL.pairs);
 		if (scatter)
-			STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)capacity, stream), "tile scatter");
+			STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)capacity, tile_order, stream), "tile scatter");
 		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, sort_longest, pairs, point_list, ranges,
 		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, stream), "tile sort");
 		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }

@@ -59,7 +59,8 @@ namespace fdgs
 		size_t tile_counters;   // [T] instance counts -> exclusive starts -> ends (count / scan / scatter passes)
 		size_t bin_ctl;         // { R, longest tile list } written by the scan, read back by the host
 		size_t tile_order;      // [T] the order in which the blend kernels take the tiles (longest lists first inside every XCD's
-		                        // band of tiles), written by the scan kernel; [T] more words of scratch behind it
+		                        // band of tiles), written by one workgroup of the scatter launch from the
+		                        // [T] counts the scan leaves behind it (at + T); [T] words of scratch at + 2 T + 4
 		size_t total;
 	};
 	static inline ImageLayout image_layout(int W, int H)
@@ -73,7 +74,7 @@ namespace fdgs
 		L.ranges = o; o = align_up(o + t * 8);
 		L.tile_counters = o; o = align_up(o + bin_counter_words((int)t) * 4);
 		L.bin_ctl = o; o = align_up(o + 16);
-		L.tile_order = o; o = align_up(o + 2 * t * 4);
+		L.tile_order = o; o = align_up(o + (3 * t + 8) * 4);
 		L.total = o;
 		return L;
 	}
@@ -112,12 +113,13 @@ namespace fdgs
 	// scatter its end.  ctl[0] = R, ctl[1] = longest tile list.
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream);
 	// host_box (optional): device pointer of a pinned host mailbox {R, longest, ticket} the kernel writes directly
-	// tile_order (optional, 2 T words): see ImageLayout
+	// tile_order (optional, 3 T + 8 words, see ImageLayout): the scan leaves a copy of the tile counts at tile_order + T
 	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, uint32_t* tile_order, hipStream_t stream);
 	// scatter / sort may be launched before the host knows num_rendered: they compare ctl[0] with `capacity` (the instances
 	// pairs / point_list hold) and leave everything alone -- the sort reports every tile empty -- when it does not fit
+	// tile_order (optional): one extra workgroup of this launch turns the scan's copy of the counts into the blend kernels' tile order
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                               const uint32_t* ctl, uint32_t capacity, hipStream_t stream);
+	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream);
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
 	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, hipStream_t stream);
 	int tile_sort_lds_cap();                                   // lists longer than this need the global scratch

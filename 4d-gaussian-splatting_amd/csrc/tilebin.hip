@@ -84,14 +84,72 @@ namespace fdgs
 		}
 	}
 
+	// Order of the tiles for the blend kernels (blend_common.h, block_of): inside every XCD's band of `band` consecutive tiles the
+	// longest lists go first, so that a blend launch ends on short tiles -- a counting sort over ORDER_BUCKETS length classes of the
+	// longest list (class 0 = the longest); the rank of a tile inside its class is whatever the LDS atomic hands out (the order only
+	// schedules work, no result depends on it).  Run by ONE extra workgroup of the scatter launch (off the forward's critical path:
+	// the scan only leaves a copy of the tile counts, which this workgroup turns into ranks in place).
+	// counts: [T] list lengths (left alone: a scatter pass that is launched a second time orders again); tmp: [T] scratch; order: [T];
+	// s_cls: 8 * ORDER_BUCKETS words of LDS.
+	constexpr int ORDER_BUCKETS = 64;
+	__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tmp, int T, int band, uint32_t gmax,
+	                                                 uint32_t* __restrict__ order, uint32_t* s_cls)
+	{
+		const int nthreads = (int)blockDim.x, lane = threadIdx.x & 63;
+		for (int k = threadIdx.x; k < 8 * ORDER_BUCKETS; k += nthreads) s_cls[k] = 0u;
+		__syncthreads();
+		const float cls_scale = (float)ORDER_BUCKETS / ((float)gmax + 1.0f);
+		const float inv_band = 1.0f / (float)band;
+		const auto band_of = [&](int t) {
+			int b = (int)((float)t * inv_band);   // t / band by a float reciprocal and one correction step either way (b < 8)
+			if (b * band > t) b--;
+			else if ((b + 1) * band <= t) b++;
+			return b;
+		};
+		for (int t = threadIdx.x; t < T; t += nthreads)
+		{
+			const uint32_t cls = (uint32_t)(ORDER_BUCKETS - 1) - min((uint32_t)(ORDER_BUCKETS - 1), (uint32_t)((float)counts[t] * cls_scale));
+			const uint32_t rank = atomicAdd(&s_cls[band_of(t) * ORDER_BUCKETS + cls], 1u);
+			tmp[t] = (cls << 24) | rank;   // read back below by this same thread
+		}
+		__syncthreads();
+		if (threadIdx.x < 8 * WAVE)
+		{
+			// exclusive scan of the class sizes of band (threadIdx.x / 64) by one wave (lane = class)
+			const uint32_t n = s_cls[threadIdx.x];
+			uint32_t inc = n;
+#pragma unroll
+			for (int o = 1; o < WAVE; o <<= 1)
+			{
+				const uint32_t u = __shfl_up(inc, o);
+				if (lane >= o) inc += u;
+			}
+			s_cls[threadIdx.x] = inc - n;
+		}
+		__syncthreads();
+		for (int t = threadIdx.x; t < T; t += nthreads)
+		{
+			const uint32_t cr = tmp[t];
+			const int b = band_of(t);
+			order[b * band + s_cls[b * ORDER_BUCKETS + (cr >> 24)] + (cr & 0xFFFFFFu)] = (uint32_t)t;
+		}
+	}
+
 	constexpr int BIN_T = 1024;
 	template <bool SCATTER>
 	__global__ void __launch_bounds__(BIN_T) tile_bin_lds_kernel(const ushort4* __restrict__ rect, const float* __restrict__ depths, int P,
 	                                                             int grid_x, int T, int rounds /* batch = rounds * BIN_T Gaussians per workgroup */,
 	                                                             uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
-	                                                             const uint32_t* __restrict__ ctl, uint32_t capacity)
+	                                                             const uint32_t* __restrict__ ctl, uint32_t capacity,
+	                                                             uint32_t* __restrict__ order /* [3 T + 8] or NULL */, int band)
 	{
-		extern __shared__ uint32_t s_hist[];   // T words
+		extern __shared__ uint32_t s_hist[];   // max(T, 8 * ORDER_BUCKETS) words
+		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
+		{
+			// the extra workgroup of the scatter launch: the blend kernels' tile order from the scan's copy of the counts
+			tile_order_block(order + T, order + 2 * T + 4, T, band, ctl[1], order, s_hist);
+			return;
+		}
 		// launched before the host knew num_rendered (capi.hip): `pairs` holds `capacity` instances -- more than that: leave everything alone
 		if (SCATTER && ctl[0] > capacity) return;
 		const int lane = threadIdx.x & 63;
@@ -156,8 +214,15 @@ namespace fdgs
 	template <bool SCATTER>
 	__global__ void __launch_bounds__(256) tile_bin_direct_kernel(const ushort4* __restrict__ rect, const float* __restrict__ depths, int P,
 	                                                              int grid_x, uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
-	                                                              const uint32_t* __restrict__ ctl, uint32_t capacity)
+	                                                              const uint32_t* __restrict__ ctl, uint32_t capacity,
+	                                                              uint32_t* __restrict__ order, int T, int band)
 	{
+		__shared__ uint32_t s_cls[8 * ORDER_BUCKETS];
+		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
+		{
+			tile_order_block(order + T, order + 2 * T + 4, T, band, ctl[1], order, s_cls);
+			return;
+		}
 		if (SCATTER && ctl[0] > capacity) return;
 		const int g = blockIdx.x * blockDim.x + threadIdx.x;
 		ushort4 r = make_ushort4(0, 0, 0, 0);
@@ -177,16 +242,13 @@ namespace fdgs
 	// exclusive scan of the tile counters by ONE workgroup; ctl[0] = R, ctl[1] = longest tile list
 	// ------------------------------------------------------------------------------------------------
 	constexpr int SCAN_T = 1024;
-	constexpr int ORDER_BUCKETS = 64;   // list lengths are ranked in 64 linear classes of the longest list
 	__global__ void __launch_bounds__(SCAN_T) tile_scan_kernel(uint32_t* __restrict__ counters, int T, int per_thread /* multiple of 4 */,
 	                                                           uint32_t* __restrict__ ctl, uint32_t* __restrict__ host_box, uint32_t ticket,
-	                                                           uint32_t* __restrict__ order /* [2 T] or NULL */, int band /* tiles per XCD */)
+	                                                           uint32_t* __restrict__ counts_copy /* [T + 3] or NULL: the counts, for tile_order_block */)
 	{
 		__shared__ uint32_t s_w[SCAN_T / WAVE], s_m[SCAN_T / WAVE];
-		__shared__ uint32_t s_cls[8 * ORDER_BUCKETS];   // tiles per (XCD band, length class) -> start of the class inside its band
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const int first = threadIdx.x * per_thread;
-		if (threadIdx.x < 8 * ORDER_BUCKETS) s_cls[threadIdx.x] = 0u;
 		// the counter array is padded to a multiple of 4 words (zeros), so the uint4 accesses stay inside it
 		uint32_t sum = 0, m = 0;
 		for (int i = 0; i < per_thread; i += 4)
@@ -214,14 +276,7 @@ namespace fdgs
 			gtot += s_w[w2];
 			gmax = max(gmax, s_m[w2]);
 		}
-		// Order of the tiles for the blend kernels (blend_common.h, block_of): inside every XCD's band of `band` consecutive tiles
-		// the longest lists go first -- a counting sort over ORDER_BUCKETS length classes (class 0 = the longest); the rank of a
-		// tile inside its class is whatever the LDS atomic hands out (the order only schedules work, no result depends on it).
-		const float cls_scale = (float)ORDER_BUCKETS / ((float)gmax + 1.0f);
-		uint32_t* const order_tmp = order ? order + T : nullptr;
 		uint32_t run = base + incl - sum;
-		const int band0 = first / band;      // the band of this thread's first tile; its tiles are consecutive
-		int bnd = band0, bnd_end = (band0 + 1) * band;
 		for (int i = 0; i < per_thread; i += 4)
 		{
 			if (first + i >= T) break;
@@ -233,50 +288,7 @@ namespace fdgs
 			o.z = run; run += v.z;
 			o.w = run; run += v.w;
 			*p = o;
-			if (order)
-			{
-				const uint32_t c4[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-				for (int c = 0; c < 4; c++)
-				{
-					const int t = first + i + c;
-					while (t >= bnd_end) { bnd++; bnd_end += band; }
-					if (t < T)
-					{
-						const uint32_t cls = (uint32_t)(ORDER_BUCKETS - 1) - min((uint32_t)(ORDER_BUCKETS - 1), (uint32_t)((float)c4[c] * cls_scale));
-						const uint32_t rank = atomicAdd(&s_cls[bnd * ORDER_BUCKETS + cls], 1u);
-						order_tmp[t] = (cls << 24) | rank;   // read back below by this same thread
-					}
-				}
-			}
-		}
-		if (order)
-		{
-			__syncthreads();
-			if (threadIdx.x < 8 * ORDER_BUCKETS)
-			{
-				// exclusive scan of the class sizes of one band by one wave (lane = class)
-				const uint32_t n = s_cls[threadIdx.x];
-				uint32_t inc = n;
-#pragma unroll
-				for (int o = 1; o < WAVE; o <<= 1)
-				{
-					const uint32_t t = __shfl_up(inc, o);
-					if (lane >= o) inc += t;
-				}
-				s_cls[threadIdx.x] = inc - n;
-			}
-			__syncthreads();
-			bnd = band0; bnd_end = (band0 + 1) * band;
-			for (int i = 0; i < per_thread; i++)
-			{
-				const int t = first + i;
-				if (t >= T) break;
-				while (t >= bnd_end) { bnd++; bnd_end += band; }
-				const uint32_t cr = order_tmp[t];
-				const int b = bnd;
-				order[b * band + s_cls[b * ORDER_BUCKETS + (cr >> 24)] + (cr & 0xFFFFFFu)] = (uint32_t)t;
-			}
+			if (counts_copy) *reinterpret_cast<uint4*>(counts_copy + first + i) = v;   // 16-byte aligned, 3 words of slack behind T
 		}
 		if (threadIdx.x == 0)
 		{
@@ -584,16 +596,20 @@ namespace fdgs
 	// ------------------------------------------------------------------------------------------------
 	// host side
 	// ------------------------------------------------------------------------------------------------
+	constexpr int NUM_XCDS_BIN = 8;                // blend_common.h NUM_XCDS
 	constexpr int BIN_LDS_MAX_TILES = 36 * 1024;   // a 144 KiB histogram stays inside the 160 KiB of a CU
 	static inline int bin_rounds(int T) { return T <= 8192 ? 1 : 4; }   // bigger histograms: fewer, longer workgroups
 
 	template <bool SCATTER>
 	static hipError_t launch_tile_bin(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                                  const uint32_t* ctl, uint32_t capacity, hipStream_t stream)
+	                                  const uint32_t* ctl, uint32_t capacity, uint32_t* order, hipStream_t stream)
 	{
 		if (P <= 0) return hipSuccess;
 		const ushort4* r4 = reinterpret_cast<const ushort4*>(rect);
 		uint2* p2 = reinterpret_cast<uint2*>(pairs);
+		const int band = div_up(T, NUM_XCDS_BIN);   // = the tiles per XCD of blend_common.h, block_of
+		if (band >= (1 << 24)) order = nullptr;
+		const int extra = (SCATTER && order) ? 1 : 0;   // one more workgroup: tile_order_block
 		if (T <= BIN_LDS_MAX_TILES)
 		{
 			// the attribute belongs to the (kernel, device) pair: set once per device this process launches on
@@ -609,33 +625,32 @@ namespace fdgs
 				if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
 			}
 			const int rounds = bin_rounds(T);
-			hipLaunchKernelGGL(tile_bin_lds_kernel<SCATTER>, dim3(div_up(P, rounds * BIN_T)), dim3(BIN_T), (size_t)T * 4, stream, r4, depths, P,
-			                   grid_x, T, rounds, counters, p2, ctl, capacity);
+			hipLaunchKernelGGL(tile_bin_lds_kernel<SCATTER>, dim3(div_up(P, rounds * BIN_T) + extra), dim3(BIN_T),
+			                   (size_t)max(T, 8 * ORDER_BUCKETS) * 4, stream, r4, depths, P, grid_x, T, rounds, counters, p2, ctl, capacity, order, band);
 		}
 		else
-			hipLaunchKernelGGL(tile_bin_direct_kernel<SCATTER>, dim3(div_up(P, 256)), dim3(256), 0, stream, r4, depths, P, grid_x, counters, p2,
-			                   ctl, capacity);
+			hipLaunchKernelGGL(tile_bin_direct_kernel<SCATTER>, dim3(div_up(P, 256) + extra), dim3(256), 0, stream, r4, depths, P, grid_x, counters, p2,
+			                   ctl, capacity, order, T, band);
 		return hipGetLastError();
 	}
 
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream)
 	{
-		return launch_tile_bin<false>(rect, nullptr, P, grid_x, T, counters, nullptr, nullptr, 0u, stream);
+		return launch_tile_bin<false>(rect, nullptr, P, grid_x, T, counters, nullptr, nullptr, 0u, nullptr, stream);
 	}
 
 	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, uint32_t* tile_order, hipStream_t stream)
 	{
 		const int per_thread = div_up(div_up(T, SCAN_T), 4) * 4;
-		const int band = div_up(T, 8);   // = the tiles per XCD of blend_common.h, block_of (NUM_XCDS)
-		if (band >= (1 << 24)) tile_order = nullptr;
-		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl, host_box, ticket, tile_order, band);
+		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl, host_box, ticket,
+		                   tile_order ? tile_order + T : nullptr);
 		return hipGetLastError();
 	}
 
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                               const uint32_t* ctl, uint32_t capacity, hipStream_t stream)
+	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream)
 	{
-		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, ctl, capacity, stream);
+		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, ctl, capacity, tile_order, stream);
 	}
 
 	// test hook: cap the list length the LDS instances take, and the crowded-bucket threshold

@@ -377,33 +377,61 @@ def test_tile_sort_long_lists(gpu_device):
 
 def test_forward_run_ahead_matches_exact_path(gpu_device):
     """The forward enqueues scatter / sort / blend before the host knows num_rendered, with buffers sized by the thread's
-    previous call (capi.hip "run-ahead"); debug mode takes the exact path (wait, then size).  A sequence of scenes that
-    makes every guess wrong in turn -- more instances than the capacity, longer lists than the sort instances launched, lists
-    that need the global scratch the buffer was sized without, then much smaller again -- must give bit-identical results
-    either way (the forward is deterministic: no float atomics)."""
-    seq = [SC("a", 3000, 160, 128, 0, 0, 0.02, 1.0, True, 4, True),      # small
-           SC("b", 30000, 320, 240, 0, 0, 0.03, 1.0, True, 4, True),     # 10 x the instances: over capacity
-           SC("c", 30000, 128, 96, 0, 0, 0.03, 1.0, True, 4, True),      # fewer instances, longer lists: other sort instances
-           SC("d", 40000, 96, 64, 0, 0, 0.03, 1.0, True, 4, True),       # lists beyond 4096: global scratch the buffer was sized without
-           SC("e", 2000, 208, 160, 0, 0, 0.01, 1.0, True, 4, True),      # tiny
-           SC("f", 20000, 320, 240, 1, 0, 0.03, 1.0, True, 4, True),     # back up
-           SC("g", 20000, 320, 240, 1, 0, 0.03, 1.0, True, 4, True)]     # same sizes again: the guess fits
+    previous call for the same (device, W, H, P) (capi.hip "run-ahead"); debug mode takes the exact path (wait, then size).  A
+    sequence of scenes of ONE size that makes every guess wrong in turn -- more instances than the capacity, longer lists than the
+    sort instances launched, lists that need the global scratch the buffer was sized without, then much smaller again -- must
+    give bit-identical results either way (the forward is deterministic: no float atomics)."""
     from fdgs import _capi
-    longest, paths = [], []
-    for k, cfg in enumerate(seq):
-        scene = synth.make_scene(cfg, seed=40 + k)
+    cfg = SC("ra", 30011, 320, 240, 0, 0, 0.03, 1.0, True, 4, True)   # a P no other test uses: the first call has no guess
+
+    def variant(k_mean, k_scale):
+        sc = synth.make_scene(cfg, seed=40)
+        sc["means3D"] = (sc["means3D"] * torch.tensor([k_mean, k_mean, 1.0])).contiguous()
+        sc["scales"] = (sc["scales"] * k_scale).contiguous()
+        return sc
+
+    seq = [("a", 1.0, 0.25),    # small splats: R ~ 55 k
+           ("b", 1.0, 1.0),     # R ~ 129 k: over the capacity guessed from a
+           ("c", 0.5, 0.45),    # drawn towards the image centre: fewer instances, lists of ~2100 where ~980 were the longest
+           ("d", 0.3, 0.45),    # lists beyond 4096: the global scratch the buffer was sized without
+           ("e", 1.0, 0.15),    # small again: everything fits
+           ("f", 1.0, 0.8),     # back up: over capacity
+           ("g", 1.0, 0.8)]     # same sizes again: the guess fits
+    longest, paths, Rs = [], [], []
+    for name, km, ks in seq:
+        scene = variant(km, ks)
         before = _capi.run_ahead_stats()
         fast, _ = run_hip(scene, gpu_device, None)
         paths.append(tuple(b - a for a, b in zip(before, _capi.run_ahead_stats())))
         exact, _ = run_hip(dict(scene, debug=True), gpu_device, None)
-        label = "run-ahead step %s" % cfg.name
+        label = "run-ahead step %s" % name
         assert fast["R"] == exact["R"], label
         for key in ("point_list", "ranges", "n_contrib", "final_T", "out_color", "out_depth", "out_flow", "radii"):
             np.testing.assert_array_equal(fast[key], exact[key], err_msg="%s %s" % (label, key))
         longest.append(int((exact["ranges"][:, 1].astype(np.int64) - exact["ranges"][:, 0]).max()))
-    print("run-ahead sequence: longest list per step", longest, "path (kept, sorted again, exact) per step", paths)
-    assert paths[1] == (0, 0, 1) and paths[3] == (0, 1, 0) and paths[4] == (1, 0, 0) and paths[6] == (1, 0, 0), paths
-    assert longest[3] > 4096 > longest[2] + longest[2] // 4 and longest[1] > 2 * longest[0] and longest[4] < longest[3] // 8
+        Rs.append(exact["R"])
+    print("run-ahead sequence: R", Rs, "longest list per step", longest, "path (kept, sorted again, exact) per step", paths)
+    assert paths == [(0, 0, 1), (0, 0, 1), (0, 1, 0), (0, 1, 0), (1, 0, 0), (0, 0, 1), (1, 0, 0)], paths
+    assert longest[3] > 4096 > longest[2] + longest[2] // 4 and longest[2] > longest[1] + longest[1] // 4 and Rs[1] > 2 * Rs[0]
+
+
+def test_run_ahead_can_be_switched_off(gpu_device):
+    """fdgs_set_run_ahead(0): every forward waits for num_rendered and sizes the binning buffer exactly (the reference's contract)."""
+    from fdgs import _capi
+    scene = synth.make_scene(SC("ro", 5000, 160, 128, 0, 0, 0.03, 1.0, True, 4, True), seed=3)
+    try:
+        _capi.lib.fdgs_set_run_ahead(0)
+        run_hip(scene, gpu_device, None)
+        before = _capi.run_ahead_stats()
+        a, _ = run_hip(scene, gpu_device, None)
+        assert tuple(y - x for x, y in zip(before, _capi.run_ahead_stats())) == (0, 0, 1)
+    finally:
+        _capi.lib.fdgs_set_run_ahead(1)
+    before = _capi.run_ahead_stats()
+    b, _ = run_hip(scene, gpu_device, None)
+    assert tuple(y - x for x, y in zip(before, _capi.run_ahead_stats())) == (1, 0, 0)
+    for key in ("point_list", "ranges", "out_color", "n_contrib"):
+        np.testing.assert_array_equal(a[key], b[key])
 
 
 @pytest.mark.parametrize("cfg", [SC("s4", 20000, 320, 240, 3, 2, 0.03, 10.0, True, 4, False), SC("s3", 9000, 208, 160, 2, 0, 0.03, 1.0, False, 3, True),
