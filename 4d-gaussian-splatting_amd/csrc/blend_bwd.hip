@@ -120,24 +120,143 @@ namespace fdgs
 		return g[0];
 	}
 
-	// slot_off: this lane's word of the record, in bytes.  The address is the uniform base plus a 32-bit byte offset
-	// (a record is 64 bytes: P < 2^26, checked by the launcher), which the atomic takes as SGPR base + VGPR offset -- one
-	// shift-add per entry instead of 64-bit pointer arithmetic.
-	template <bool AUX>
-	__device__ __forceinline__ void reduce_and_add(float (&g)[12], float* gacc, uint32_t slot_off, bool slot_writer, uint32_t eid)
+	// Joint row reduction of the NS = 9 values of TWO entries (generated and checked by tools/gen_reduce.py: every instruction
+	// simulated on symbolic lane values).  a[] = entry 0, b[] = entry 1.  Step 1 (lane ^ 8) sends entry 0 to lanes 0-7 and entry 1
+	// to lanes 8-15 of every row, steps 2-4 are the halving butterfly inside the half-row.  On return lane h = lane & 7 of a half-row
+	// holds, summed over the 16 lanes of its row,
+	//   A0: slots [0, 2, 3, None, 5, 7, 8, None]
+	//   A1: slots [1, None, 4, None, 6, None, None, None]
+	// (None: a duplicate or partial that must not be used).
+	__device__ __forceinline__ void pair_row_reduce9(float (&a)[12], const float (&b)[12])
 	{
-		float total = AUX ? row_transpose_reduce12(g) : row_transpose_reduce9(g);
-		total += __shfl_xor(total, 16);       // across the four 16-lane rows
-		total += __shfl_xor(total, 32);
-		if (slot_writer) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gacc) + (eid * (uint32_t)(GRAD_ACC_WORDS * 4) + slot_off)), total);
+		const unsigned long long m1 = 0xCCCCCCCCCCCCCCCCull, m0 = 0xAAAAAAAAAAAAAAAAull;
+		asm volatile(
+			"s_nop 1\n\t"
+			"v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %0, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %1, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %2, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %3, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %4, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %5, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %6, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %7, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %8, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %0, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %1, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %2, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %3, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %3, %18\n\t"
+			"v_cndmask_b32_e64 %1, %1, %4, %18\n\t"
+			"v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %2, %19"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
+			: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "s"(m1), "s"(m0));
 	}
+
+	// Joint row reduction of the NS = 12 values of TWO entries (generated and checked by tools/gen_reduce.py: every instruction
+	// simulated on symbolic lane values).  a[] = entry 0, b[] = entry 1.  Step 1 (lane ^ 8) sends entry 0 to lanes 0-7 and entry 1
+	// to lanes 8-15 of every row, steps 2-4 are the halving butterfly inside the half-row.  On return lane h = lane & 7 of a half-row
+	// holds, summed over the 16 lanes of its row,
+	//   A0: slots [0, 2, 3, 5, 6, 8, 9, 11]
+	//   A1: slots [1, None, 4, None, 7, None, 10, None]
+	// (None: a duplicate or partial that must not be used).
+	__device__ __forceinline__ void pair_row_reduce12(float (&a)[12], const float (&b)[12])
+	{
+		const unsigned long long m1 = 0xCCCCCCCCCCCCCCCCull, m0 = 0xAAAAAAAAAAAAAAAAull;
+		asm volatile(
+			"s_nop 1\n\t"
+			"v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %10, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %11, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+			"v_add_f32_dpp %0, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %1, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %2, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %5, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %6, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %7, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %8, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %9, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %10, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %11, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+			"v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %0, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %1, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %2, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %3, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %4, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %5, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+			"v_add_f32_dpp %5, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %3, %24\n\t"
+			"v_cndmask_b32_e64 %1, %1, %4, %24\n\t"
+			"v_cndmask_b32_e64 %2, %2, %5, %24\n\t"
+			"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+			"v_cndmask_b32_e64 %0, %0, %2, %25"
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
+			: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "v"(b[10]), "v"(b[11]), "s"(m1), "s"(m0));
+	}
+
+	// Per-wave LDS staging of the row sums: ACC_GROUP list entries x 4 rows x 16 positions.  What a lane holds after the DPP
+	// reduction (the sum over the 16 pixels of its row) is STORED there -- one ds_write per pair of entries -- and every
+	// ACC_GROUP / 2 queue pairs the staging area is drained: 16 lanes per entry add up the four rows of one position each and the
+	// lanes that hold a record word issue ONE global_atomic_add_f32 instruction per four entries (still one memory-side request
+	// per entry: a record is one 64-byte segment).  This replaces two dependent ds_bpermute round trips, two adds and an atomic per
+	// entry.  (LDS float atomics instead of the plain stores -- the four rows adding into one word -- were measured: ds_add_f32 /
+	// ds_wrxchg retire a few lanes per cycle, the kernel took 0.98 ms instead of 0.29.)
+	// Position of gradient slot s of an entry: AUX (s = record word 0..11): (s / 3) * 4 + s % 3; colour-only (slots = words
+	// 0,1,2,6..11): 0,1,2,4,5,8,9,10,12 -- where the joint reduction above leaves them (lane h of a half-row: positions 2 h and
+	// 2 h + 1); the other positions hold duplicates nobody reads.
+	constexpr int ACC_GROUP = 8;
 
 	// AUX = false: only the colour image carries an upstream gradient (dL_dout_depth / _alpha / _flow are NULL = zero),
 	// the usual case in training (photometric loss on the render only): the depth / flow / mask terms drop out.
 	typedef float v2f __attribute__((ext_vector_type(2)));
 
 	template <bool AUX>
-	__global__ void __launch_bounds__(WAVE) blend_bwd_kernel(
+	__device__ __forceinline__ void blend_bwd_body(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
 		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
 		const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -190,15 +309,58 @@ namespace fdgs
 		// accumulator record: colour r,g,b 0-2, depth 3, flow 4-5, then the moments of q = G dL/dalpha: q dx, q dy 6-7,
 		// q dx^2, q dy^2 8-9, q dx dy 10, q 11 (preprocess_bwd turns them into dL/dmean2D, dL/dconic, dL/dopacity).  One record = one 64-B segment, so the 12-lane atomic instruction is ONE memory-side
 		// request instead of five (the reference scatters into five arrays, backward.cu:1116-1133).
-		const uint32_t slot_off = (uint32_t)(lane & 15) * 4u;
-		const bool slot_writer = lane < NG && (AUX || lane < 3 || lane > 5);
+		__shared__ __attribute__((aligned(16))) float s_acc[ACC_GROUP * 64];   // [entry][row][position]
+		char* const acc_b = reinterpret_cast<char*>(s_acc);
+		// pair path: lanes 0-7 of a row hold entry 0, lanes 8-15 entry 1; lane h of the half-row: positions 2 h and 2 h + 1
+		const uint32_t off_pair = (uint32_t)((lane >> 3) & 1) * 256u + (uint32_t)(lane >> 4) * 64u + (uint32_t)(lane & 7) * 8u;
+		// single-entry path: after row_transpose_reduce* lane c = lane & 15 of every row holds record word c
+		const int wl = lane & 15;
+		int pos_of_word, word_of_pos;
+		if (AUX)
+		{
+			pos_of_word = wl < NG ? (wl / 3) * 4 + wl % 3 : 3;
+			word_of_pos = (wl & 3) == 3 ? -1 : (wl >> 2) * 3 + (wl & 3);
+		}
+		else
+		{
+			pos_of_word = wl < 3 ? wl : (wl == 6 ? 4 : wl == 7 ? 5 : (wl >= 8 && wl <= 10) ? wl : wl == 11 ? 12 : 3);
+			word_of_pos = wl < 3 ? wl : (wl == 4 ? 6 : wl == 5 ? 7 : (wl >= 8 && wl <= 10) ? wl : wl == 12 ? 11 : -1);
+		}
+		const uint32_t off_single = (uint32_t)(lane >> 4) * 64u + (uint32_t)pos_of_word * 4u;
+		// drain: this lane takes position lane & 15 of entry (lane >> 4) + 4 it; woff = byte offset of the record word behind the
+		// position (negative: a position nobody reads)
+		const int woff = word_of_pos < 0 ? -1 : word_of_pos * 4;
+		const uint32_t lane_entry_bit = 1u << (lane >> 4);
+		const float* const acc_lane = s_acc + (lane >> 4) * 64 + wl;   // row 0 of this lane's (entry, position); rows: + 16 floats each
+		// the Gaussian id of entry e = 4 it + (lane >> 4) of the group that starts at queue pair gp0: word 2 + (e & 1) of s_q[6][gp0 + e / 2]
+		const uint32_t* const id_lane = reinterpret_cast<const uint32_t*>(&s_q[6][lane >> 5]) + 2 + ((lane >> 4) & 1);
+		uint32_t grp_mask = 0u;   // entries of the current group that were staged (uniform)
+		auto drain = [&](const int gp0, const uint32_t mask) __attribute__((always_inline))
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // compiler ordering only: the LDS executes a wave's operations in order
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int it = 0; it < ACC_GROUP / 4; it++)
+			{
+				if ((mask >> (4 * it)) & 0xFu)
+				{
+					const float* r = acc_lane + it * 256;
+					const float v = (r[0] + r[16]) + (r[32] + r[48]);
+					const uint32_t eid = id_lane[(gp0 + 2 * it) * 4];
+					if (woff >= 0 && (mask & (lane_entry_bit << (4 * it))))
+						atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gacc) + (eid * (uint32_t)(GRAD_ACC_WORDS * 4) + (uint32_t)woff)), v);
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		};
 
 		float S = 0.f, Lc = 0.f, last_alpha = 0.f;
 
 		// One queue entry against this lane's pixel, after the packed head: d = mean2D - pixel, power, G = exp(power), alpha;
 		// colour (cr, cg, cb), depth, flow of the entry; active = this pixel takes part; eid = Gaussian id.
 		auto entry = [&](const float dx, const float dy, const float power, const float G, const float alpha, const float cr, const float cg,
-		                 const float cb, const float cdepth, const float cfx, const float cfy, const lanemask active, const uint32_t eid) __attribute__((always_inline))
+		                 const float cb, const float cdepth, const float cfx, const float cfy, const lanemask active, const int e_in_group) __attribute__((always_inline))
 		{
 			// Branch-free: a lane that skips this entry runs the same instructions with
 			// alpha = G = 0, which leaves T and the recurrence unchanged and makes all 12 products zero.
@@ -242,14 +404,15 @@ namespace fdgs
 			g[9] = qy * dy;
 			g[10] = qx * dy;
 			g[11] = q;
-			reduce_and_add<AUX>(g, gacc, slot_off, slot_writer, eid);
+			const float total = AUX ? row_transpose_reduce12(g) : row_transpose_reduce9(g);
+			*reinterpret_cast<float*>(acc_b + (off_single + (uint32_t)e_in_group * 256u)) = total;
 		};
 
 		// Both entries of a pair have contributing pixels (the common case): the same arithmetic as `entry` twice, but
 		// everything that is not part of the sequential T / S recurrences runs packed on the two entries.
 		auto entry_pair = [&](const v2f dx, const v2f dy, const v2f G, const float alpha0, const float alpha1, const v2f cr, const v2f cg,
 		                      const v2f cb, const v2f cdepth, const v2f cfx, const v2f cfy, const lanemask act0, const lanemask act1,
-		                      const uint32_t eid0, const uint32_t eid1) __attribute__((always_inline))
+		                      const int pair_in_group) __attribute__((always_inline))
 		{
 			const v2f alpha_e = { mask_select(act0, alpha0, 0.0f), mask_select(act1, alpha1, 0.0f) };
 			const v2f G_e = { mask_select(act0, G.x, 0.0f), mask_select(act1, G.y, 0.0f) };
@@ -277,11 +440,18 @@ namespace fdgs
 			{
 				const v2f g3 = dcd * dL_depth, g4 = dcd * dLf0, g5 = dcd * dLf1;
 				ga[3] = g3.x; ga[4] = g4.x; ga[5] = g5.x; gb[3] = g3.y; gb[4] = g4.y; gb[5] = g5.y;
+				ga[6] = qx.x; ga[7] = qy.x; ga[8] = qxx.x; ga[9] = qyy.x; ga[10] = qxy.x; ga[11] = q.x;
+				gb[6] = qx.y; gb[7] = qy.y; gb[8] = qxx.y; gb[9] = qyy.y; gb[10] = qxy.y; gb[11] = q.y;
+				pair_row_reduce12(ga, gb);
 			}
-			ga[6] = qx.x; ga[7] = qy.x; ga[8] = qxx.x; ga[9] = qyy.x; ga[10] = qxy.x; ga[11] = q.x;
-			gb[6] = qx.y; gb[7] = qy.y; gb[8] = qxx.y; gb[9] = qyy.y; gb[10] = qxy.y; gb[11] = q.y;
-			reduce_and_add<AUX>(ga, gacc, slot_off, slot_writer, eid0);
-			reduce_and_add<AUX>(gb, gacc, slot_off, slot_writer, eid1);
+			else
+			{
+				// colour-only: nine slots, the moments follow the colours directly
+				ga[3] = qx.x; ga[4] = qy.x; ga[5] = qxx.x; ga[6] = qyy.x; ga[7] = qxy.x; ga[8] = q.x;
+				gb[3] = qx.y; gb[4] = qy.y; gb[5] = qxx.y; gb[6] = qyy.y; gb[7] = qxy.y; gb[8] = q.y;
+				pair_row_reduce9(ga, gb);
+			}
+			*reinterpret_cast<float2*>(acc_b + (off_pair + (uint32_t)pair_in_group * 512u)) = make_float2(ga[0], ga[1]);
 		};
 
 		for (int top = wave_last; top > 0; top -= WAVE)
@@ -332,7 +502,7 @@ namespace fdgs
 			{
 				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i], Q5 = s_q[5][i];
 				const uint4 pi = *reinterpret_cast<const uint4*>(&s_q[6][i]);
-				const uint2 pp = make_uint2(pi.x, pi.y), ii = make_uint2(pi.z, pi.w);
+				const uint2 pp = make_uint2(pi.x, pi.y);   // (.z, .w: the Gaussian ids, read by the drain)
 				// packed head for both entries, with the reference's association per element (forward.cu:585,
 				// backward.cu:1036): keeps alpha -- and with it the alpha >= 1/255 decision -- within an ulp of the oracle's
 				// (a cheaper factored form flipped cliff pairs and was dropped)
@@ -348,15 +518,46 @@ namespace fdgs
 				const lanemask act0 = mask_of((int)pp.x < last_contributor) & mask_of(!(power.x > 0.0f)) & mask_of(!(alpha0 < 1.0f / 255.0f));
 				const lanemask act1 = mask_of((int)pp.y < last_contributor) & mask_of(!(power.y > 0.0f)) & mask_of(!(alpha1 < 1.0f / 255.0f));
 				const bool any0 = act0 != 0ull, any1 = act1 != 0ull;
+				const int ip = i & (ACC_GROUP / 2 - 1);
 				if (any0 && any1)
+				{
 					entry_pair(dx, dy, G, alpha0, alpha1, v2f{ Q3.x, Q3.y }, v2f{ Q3.z, Q3.w }, v2f{ Q4.x, Q4.y }, v2f{ Q4.z, Q4.w },
-					           v2f{ Q5.x, Q5.y }, v2f{ Q5.z, Q5.w }, act0, act1, ii.x, ii.y);
-				else if (any0) entry(dx.x, dy.x, power.x, G.x, alpha0, Q3.x, Q3.z, Q4.x, Q4.z, Q5.x, Q5.z, act0, ii.x);
-				else if (any1) entry(dx.y, dy.y, power.y, G.y, alpha1, Q3.y, Q3.w, Q4.y, Q4.w, Q5.y, Q5.w, act1, ii.y);
+					           v2f{ Q5.x, Q5.y }, v2f{ Q5.z, Q5.w }, act0, act1, ip);
+					grp_mask |= 3u << (2 * ip);
+				}
+				else if (any0)
+				{
+					entry(dx.x, dy.x, power.x, G.x, alpha0, Q3.x, Q3.z, Q4.x, Q4.z, Q5.x, Q5.z, act0, 2 * ip);
+					grp_mask |= 1u << (2 * ip);
+				}
+				else if (any1)
+				{
+					entry(dx.y, dy.y, power.y, G.y, alpha1, Q3.y, Q3.w, Q4.y, Q4.w, Q5.y, Q5.w, act1, 2 * ip + 1);
+					grp_mask |= 2u << (2 * ip);
+				}
+				if (ip == ACC_GROUP / 2 - 1 || i == npairs - 1)
+				{
+					if (grp_mask) drain(i - ip, grp_mask);
+					grp_mask = 0u;
+				}
 			}
 			__syncthreads();
 		}
 	}
+
+	// Two entry points: the colour-only kernel (the training step: photometric loss on the render only) and the general one.
+#define FDGS_BWD_PARAMS \
+		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records, \
+		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg, \
+		const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, \
+		const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_masks, \
+		const float* __restrict__ dL_dpix_flow, float* __restrict__ gacc
+#define FDGS_BWD_ARGS ranges, point_list, records, tile_order, W, H, grid_x, ntiles, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_masks, dL_dpix_flow, gacc
+	template <bool AUX> __global__ void __launch_bounds__(WAVE) blend_bwd_kernel(FDGS_BWD_PARAMS);
+	template <> __global__ void __launch_bounds__(WAVE) blend_bwd_kernel<false>(FDGS_BWD_PARAMS) { blend_bwd_body<false>(FDGS_BWD_ARGS); }
+	template <> __global__ void __launch_bounds__(WAVE) blend_bwd_kernel<true>(FDGS_BWD_PARAMS) { blend_bwd_body<true>(FDGS_BWD_ARGS); }
+#undef FDGS_BWD_PARAMS
+#undef FDGS_BWD_ARGS
 
 	hipError_t launch_blend_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                            const float* records, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,

@@ -323,7 +323,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		if (scatter)
 			STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)capacity, tile_order, stream), "tile scatter");
 		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, sort_longest, pairs, point_list, ranges,
-		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, stream), "tile sort");
+		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, tile_order, stream), "tile sort");
 		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
 		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, stream), "blend_fwd");
 		return FDGS_OK;
@@ -374,7 +374,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		{
 			StageTimer timer__(FDGS_STAGE_TILE_SORT, stream);
 			sorted = launch_tile_sort(counters, T, longest, (const uint32_t*)(bin + BL.pairs), point_list, ranges,
-			                          extra ? extra : (has_scratch ? (void*)(bin + BL.big_scratch) : nullptr), ctl, (uint32_t)ahead_cap, stream);
+			                          extra ? extra : (has_scratch ? (void*)(bin + BL.big_scratch) : nullptr), ctl, (uint32_t)ahead_cap, tile_order, stream);
 		}
 		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");   // stream-ordered: after the sort, whether it was launched or not
 		HIP_TRY(sorted, "tile sort");

@@ -120,8 +120,9 @@ namespace fdgs
 	// tile_order (optional): one extra workgroup of this launch turns the scan's copy of the counts into the blend kernels' tile order
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
 	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream);
+	// tile_order (optional): the order the scatter launch wrote -- the sort takes the tiles in it too (longest lists first)
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
-	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, hipStream_t stream);
+	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, const uint32_t* tile_order, hipStream_t stream);
 	int tile_sort_lds_cap();                                   // lists longer than this need the global scratch
 	void tile_sort_debug_limits(int lds_cap, int rank_max);    // test hook (fdgs_debug_tile_sort_limits); <= 0 restores the default
 

@@ -91,7 +91,8 @@ namespace fdgs
 	// the scan only leaves a copy of the tile counts, which this workgroup turns into ranks in place).
 	// counts: [T] list lengths (left alone: a scatter pass that is launched a second time orders again); tmp: [T] scratch; order: [T];
 	// s_cls: 8 * ORDER_BUCKETS words of LDS.
-	constexpr int ORDER_BUCKETS = 64;
+	constexpr int NUM_XCDS_BIN = 8;     // blend_common.h NUM_XCDS
+	constexpr int ORDER_BUCKETS = 64;   // = WAVE: one wave scans the classes of a band
 	__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tmp, int T, int band, uint32_t gmax,
 	                                                 uint32_t* __restrict__ order, uint32_t* s_cls)
 	{
@@ -113,10 +114,10 @@ namespace fdgs
 			tmp[t] = (cls << 24) | rank;   // read back below by this same thread
 		}
 		__syncthreads();
-		if (threadIdx.x < 8 * WAVE)
+		for (int k = threadIdx.x; k < 8 * ORDER_BUCKETS; k += nthreads)   // whole waves (the workgroup has 256 or 1024 threads)
 		{
-			// exclusive scan of the class sizes of band (threadIdx.x / 64) by one wave (lane = class)
-			const uint32_t n = s_cls[threadIdx.x];
+			// exclusive scan of the class sizes of band k / 64 by one wave (lane = class)
+			const uint32_t n = s_cls[k];
 			uint32_t inc = n;
 #pragma unroll
 			for (int o = 1; o < WAVE; o <<= 1)
@@ -124,7 +125,7 @@ namespace fdgs
 				const uint32_t u = __shfl_up(inc, o);
 				if (lane >= o) inc += u;
 			}
-			s_cls[threadIdx.x] = inc - n;
+			s_cls[k] = inc - n;
 		}
 		__syncthreads();
 		for (int t = threadIdx.x; t < T; t += nthreads)
@@ -376,13 +377,25 @@ namespace fdgs
 	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
 	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
 	                                                           int lds_cap, int rank_max, const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                           int last /* no further instance takes what this one leaves */)
+	                                                           int last /* no further instance takes what this one leaves */,
+	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T, int band)
 	{
+		// Which tile: with `order` (the blend kernels' tile order, written by the scatter launch: inside every XCD's band of tiles
+		// the longest lists first) workgroup b takes slot (b % 8) * band + b / 8 of it -- the long lists start first and the launch
+		// ends on short ones; without: tile b.
+		int tile = (int)blockIdx.x;
+		if (order != nullptr)
+		{
+			const int slot = ((int)blockIdx.x % NUM_XCDS_BIN) * band + (int)blockIdx.x / NUM_XCDS_BIN;
+			if ((int)blockIdx.x / NUM_XCDS_BIN >= band || slot >= T) return;
+			tile = (int)order[slot];
+		}
+		else if (tile >= T) return;
 		// launched before the host knew num_rendered: if the buffers are too small the scatter pass did not run either (the counters
 		// are not list ends) -- every tile is reported empty, so that whatever is queued behind reads nothing, and the host starts over
 		if (ctl[0] > capacity)
 		{
-			if (n_lo == 0 && threadIdx.x == 0) ranges[blockIdx.x] = make_uint2(0u, 0u);
+			if (n_lo == 0 && threadIdx.x == 0) ranges[tile] = make_uint2(0u, 0u);
 			return;
 		}
 		// LDS: lds_cap + TS_PAD depth keys, then lds_cap ids, in bucket order (8 lds_cap + 4 TS_PAD bytes); the same
@@ -397,10 +410,10 @@ namespace fdgs
 #ifdef FDGS_TS_TIMELINE
 		unsigned long long tl_prev = __builtin_readcyclecounter();
 #endif
-		const uint32_t start = blockIdx.x == 0 ? 0u : list_end[blockIdx.x - 1];
-		const uint32_t end = list_end[blockIdx.x];
+		const uint32_t start = tile == 0 ? 0u : list_end[tile - 1];
+		const uint32_t end = list_end[tile];
 		const int n = (int)(end - start);
-		if (n_lo == 0 && tid == 0) ranges[blockIdx.x] = n > 0 ? make_uint2(start, end) : make_uint2(0u, 0u);   // identifyTileRanges leaves empty tiles at the memset's (0,0)
+		if (n_lo == 0 && tid == 0) ranges[tile] = n > 0 ? make_uint2(start, end) : make_uint2(0u, 0u);   // identifyTileRanges leaves empty tiles at the memset's (0,0)
 		if (n <= n_lo) return;
 		if (n == 1)
 		{
@@ -596,7 +609,6 @@ namespace fdgs
 	// ------------------------------------------------------------------------------------------------
 	// host side
 	// ------------------------------------------------------------------------------------------------
-	constexpr int NUM_XCDS_BIN = 8;                // blend_common.h NUM_XCDS
 	constexpr int BIN_LDS_MAX_TILES = 36 * 1024;   // a 144 KiB histogram stays inside the 160 KiB of a CU
 	static inline int bin_rounds(int T) { return T <= 8192 ? 1 : 4; }   // bigger histograms: fewer, longer workgroups
 
@@ -664,14 +676,16 @@ namespace fdgs
 
 	template <int THREADS>
 	static void launch_sort_instance(const uint32_t* counters, int T, const uint2* pairs, uint32_t* point_list, uint2* ranges, u64* big,
-	                                 int n_lo, int cap, int rank_max, const uint32_t* ctl, uint32_t capacity, bool last, hipStream_t stream)
+	                                 int n_lo, int cap, int rank_max, const uint32_t* ctl, uint32_t capacity, bool last, const uint32_t* order,
+	                                 hipStream_t stream)
 	{
-		hipLaunchKernelGGL((tile_sort_kernel<THREADS>), dim3(T), dim3(THREADS), (size_t)cap * 8 + TS_PAD * 4, stream, counters, pairs, point_list,
-		                   ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0);
+		const int band = div_up(T, NUM_XCDS_BIN);
+		hipLaunchKernelGGL((tile_sort_kernel<THREADS>), dim3(order ? band * NUM_XCDS_BIN : T), dim3(THREADS), (size_t)cap * 8 + TS_PAD * 4, stream, counters, pairs,
+		                   point_list, ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0, order, T, band);
 	}
 
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
-	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, hipStream_t stream)
+	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, const uint32_t* tile_order, hipStream_t stream)
 	{
 		const int lds_cap = g_lds_cap.load(), rank_max = g_rank_max.load();
 		const uint2* p2 = reinterpret_cast<const uint2*>(pairs);
@@ -687,13 +701,14 @@ namespace fdgs
 		const int c1 = min(128 * TS_ITEMS, lds_cap), c2 = min(256 * TS_ITEMS, lds_cap), c3 = min(512 * TS_ITEMS, lds_cap);
 		const auto lds_keys = [&](int c) { return min(c, max(64, div_up(longest_lds, 64) * 64)); };
 		const bool overflow = max_count > lds_cap;   // somebody has to take the global path
+		if (div_up(T, NUM_XCDS_BIN) >= (1 << 24)) tile_order = nullptr;   // no order was written (launch_tile_bin)
 		if (max_count <= c1 || c2 == c1)
-			launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, stream);
+			launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, tile_order, stream);
 		else
 		{
 			const bool second = max_count > c2 && c3 > c2;
-			launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, stream);
-			if (second) launch_sort_instance<512>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c2, lds_keys(c3), rank_max, ctl, capacity, true, stream);
+			launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, tile_order, stream);
+			if (second) launch_sort_instance<512>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c2, lds_keys(c3), rank_max, ctl, capacity, true, tile_order, stream);
 		}
 		return hipGetLastError();
 	}
