@@ -52,7 +52,7 @@ class FdgsScene(_Sized):
 
 class FdgsForwardOut(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
-                ("out_means3D", _fp), ("covs_com", _fp), ("split_colour", C.c_int32)]
+                ("out_means3D", _fp), ("covs_com", _fp), ("preprocessed", C.c_int32), ("split_colour", C.c_int32)]
 
 
 class FdgsBackwardIn(_Sized):
@@ -82,7 +82,7 @@ class FdgsAdamSegment(C.Structure):
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
-EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_mark_visible", "fdgs_geometry_bytes",
+EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_preprocess_batch", "fdgs_sh_backward_batch", "fdgs_mark_visible", "fdgs_geometry_bytes",
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
@@ -101,6 +101,12 @@ def _load():
     lib.fdgs_rasterize_backward.argtypes = [C.POINTER(FdgsScene), C.POINTER(FdgsBackwardIn),
                                             C.POINTER(FdgsBackwardOut), C.c_void_p]
     lib.fdgs_rasterize_backward.restype = C.c_int
+    lib.fdgs_preprocess_batch.argtypes = [C.c_int32, C.POINTER(C.POINTER(FdgsScene)), C.POINTER(C.POINTER(FdgsForwardOut)), ALLOC_FN,
+                                          C.POINTER(C.c_void_p), C.c_void_p]
+    lib.fdgs_preprocess_batch.restype = C.c_int
+    lib.fdgs_sh_backward_batch.argtypes = [C.c_int32, C.POINTER(C.POINTER(FdgsScene)), C.POINTER(C.POINTER(FdgsBackwardIn)),
+                                           C.POINTER(C.POINTER(FdgsBackwardOut)), C.c_void_p]
+    lib.fdgs_sh_backward_batch.restype = C.c_int
     lib.fdgs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fdgs_mark_visible.restype = C.c_int
     lib.fdgs_geometry_bytes.argtypes = [C.c_int32]

@@ -237,8 +237,10 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	struct Aux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 	static thread_local Aux aux_of[FDGS_MAX_DEVICES];
 	Aux& aux = aux_of[dev_id];
-	const bool split = out->split_colour != 0 && s.shs != nullptr && !debug;
-	if (split)
+	const bool pre = out->preprocessed != 0;   // fdgs_preprocess_batch ran the preprocess of this view (same stream, same buffers)
+	const bool split = out->split_colour != 0 && s.shs != nullptr && !debug && !pre;
+	if (pre) { /* nothing to launch */ }
+	else if (split)
 	{
 		if (!aux.stream)
 		{
@@ -430,6 +432,8 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	// the forward's tile order (left in the image buffer by the scan); not there for P == 0 (returned above) or with FDGS_TILE_ORDER=0
 	static const bool bwd_order = []() { const char* e = getenv("FDGS_TILE_ORDER"); return !(e && e[0] == '0'); }();
 	const int stages = (out->stage_mask & 3) ? (out->stage_mask & 3) : 3;
+	if ((out->stage_mask & 4) && s.shs && !out->sh_stage)
+		return fail(FDGS_ERR_INVALID_ARG, "stage_mask + 4 (SH backward left to fdgs_sh_backward_batch) needs sh_stage");
 	if (stages & 1)
 	{
 		// the packed accumulator records of the blend backward start from zero
@@ -438,10 +442,82 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 		if (R > 0)
 			STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
 			                       bwd_order ? (const uint32_t*)(img + IL.tile_order) : nullptr, (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
-		STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
+		if (!(out->stage_mask & 4)) STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
 	}
 	if (stages & 2)
 		STAGE(FDGS_STAGE_PREPROCESS_BWD, launch_preprocess_bwd(s, *in, *out, geom, stream), "preprocess_bwd");
+	return FDGS_OK;
+}
+
+// the views of a batch must describe the same Gaussians: sizes, degrees, flags and the shared tensors
+static int check_same_gaussians(const fdgs_scene& a, const fdgs_scene& b, int v)
+{
+	if (a.P != b.P || a.M != b.M || a.D != b.D || a.D_t != b.D_t || a.W != b.W || a.H != b.H || a.rot_4d != b.rot_4d ||
+	    a.gaussian_dim != b.gaussian_dim || a.force_sh_3d != b.force_sh_3d || a.raw_params != b.raw_params ||
+	    a.analytic_sh_grad != b.analytic_sh_grad || a.time_duration != b.time_duration || a.means3D != b.means3D || a.shs != b.shs ||
+	    a.ts != b.ts || a.opacities != b.opacities || a.scales != b.scales || a.rotations != b.rotations)
+		return fail(FDGS_ERR_INVALID_ARG, "view %d of the batch does not describe the same Gaussians as view 0 (sizes, degrees, flags and the parameter tensors must be shared)", v);
+	return FDGS_OK;
+}
+
+extern "C" int fdgs_preprocess_batch(int32_t num_views, const fdgs_scene* const* scenes, const fdgs_forward_out* const* outs,
+                                     fdgs_alloc_fn alloc, void* const* alloc_users, void* stream_v)
+{
+	g_err[0] = 0;
+	if (num_views < 1 || num_views > 64 || !scenes || !outs || !alloc || !alloc_users) return fail(FDGS_ERR_INVALID_ARG, "fdgs_preprocess_batch: bad arguments");
+	hipStream_t stream = (hipStream_t)stream_v;
+	char* geoms[64];
+	for (int v = 0; v < num_views; v++)
+	{
+		if (!scenes[v] || !outs[v]) return fail(FDGS_ERR_INVALID_ARG, "fdgs_preprocess_batch: view %d is NULL", v);
+		CHECK_STRUCT(scenes[v], fdgs_scene);
+		CHECK_STRUCT(outs[v], fdgs_forward_out);
+		int rc = check_scene(scenes[v]);
+		if (rc != FDGS_OK) return rc;
+		if ((rc = check_same_gaussians(*scenes[0], *scenes[v], v)) != FDGS_OK) return rc;
+		if (scenes[v]->P > 0 && (!outs[v]->radii || !outs[v]->out_means3D)) return fail(FDGS_ERR_INVALID_ARG, "forward outputs must not be NULL");
+	}
+	const fdgs_scene& s0 = *scenes[0];
+	if (s0.P == 0) return FDGS_OK;   // the views' forward calls handle the empty model themselves
+	const bool debug = s0.debug != 0;
+	const GeomLayout GL = geom_layout(s0.P);
+	const ImageLayout IL = image_layout(s0.W, s0.H);
+	for (int v = 0; v < num_views; v++)
+	{
+		geoms[v] = (char*)alloc(alloc_users[v], FDGS_BUF_GEOMETRY, GL.total);
+		char* img = (char*)alloc(alloc_users[v], FDGS_BUF_IMAGE, IL.total);
+		if (!geoms[v] || !img) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL");
+		uint32_t* counters = (uint32_t*)(img + IL.tile_counters);
+		// with SH: geometry now, colours for all views below; precomputed colours: the whole preprocess per view
+		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(*scenes[v], *outs[v], geoms[v], counters, s0.shs ? 1 : 0, stream), "preprocess_fwd (geometry)");
+	}
+	if (s0.shs) STAGE(FDGS_STAGE_COLOUR_FWD, launch_colour_batch(num_views, scenes, outs, geoms, stream), "colour batch");
+	return FDGS_OK;
+}
+
+extern "C" int fdgs_sh_backward_batch(int32_t num_views, const fdgs_scene* const* scenes, const fdgs_backward_in* const* ins,
+                                      const fdgs_backward_out* const* outs, void* stream_v)
+{
+	g_err[0] = 0;
+	if (num_views < 1 || num_views > 64 || !scenes || !ins || !outs) return fail(FDGS_ERR_INVALID_ARG, "fdgs_sh_backward_batch: bad arguments");
+	hipStream_t stream = (hipStream_t)stream_v;
+	for (int v = 0; v < num_views; v++)
+	{
+		if (!scenes[v] || !ins[v] || !outs[v]) return fail(FDGS_ERR_INVALID_ARG, "fdgs_sh_backward_batch: view %d is NULL", v);
+		CHECK_STRUCT(scenes[v], fdgs_scene);
+		CHECK_STRUCT(ins[v], fdgs_backward_in);
+		CHECK_STRUCT(outs[v], fdgs_backward_out);
+		int rc = check_scene(scenes[v]);
+		if (rc != FDGS_OK) return rc;
+		if ((rc = check_same_gaussians(*scenes[0], *scenes[v], v)) != FDGS_OK) return rc;
+		if (scenes[v]->P > 0 && scenes[v]->shs && (!ins[v]->radii || !ins[v]->out_means3D || !ins[v]->geom_buffer || !outs[v]->grad_accum || !outs[v]->sh_stage))
+			return fail(FDGS_ERR_INVALID_ARG, "fdgs_sh_backward_batch: view %d needs radii, out_means3D, geom_buffer, grad_accum and sh_stage", v);
+		for (int w = 0; w < v; w++)
+			if (scenes[v]->P > 0 && (outs[w]->grad_accum == outs[v]->grad_accum || outs[w]->sh_stage == outs[v]->sh_stage))
+				return fail(FDGS_ERR_INVALID_ARG, "fdgs_sh_backward_batch: views %d and %d share grad_accum / sh_stage", w, v);
+	}
+	const bool debug = scenes[0]->debug != 0;
+	STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd_batch(num_views, scenes, ins, outs, stream), "sh_bwd batch");
 	return FDGS_OK;
 }
 

@@ -103,6 +103,10 @@ namespace fdgs
 	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, int part,
 	                                 hipStream_t stream);   // part 0: one launch; 1 / 2: geometry / colour halves
 
+	// SH colours of several views of the same Gaussians in one pass over the coefficients (after the views' part-1 launches)
+	hipError_t launch_colour_batch(int nviews, const fdgs_scene* const* views, const fdgs_forward_out* const* outs, char* const* geoms,
+	                               hipStream_t stream);
+
 	// Stable LSD radix sort of (key,value) u32 pairs on key bits [bit_lo, bit_hi) (radix_sort.hip; used by knn.hip).
 	// keys[0]/vals[0] hold the input; *result receives the index (0/1) of the buffers holding the output.
 	hipError_t radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int n, int bit_lo, int bit_hi,
@@ -138,6 +142,10 @@ namespace fdgs
 	// SH / 4D-SH backward (coalesced); must run after the blend backward and before launch_preprocess_bwd
 	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                         const char* geom, hipStream_t stream);
+
+	// SH backward (deferred mode: stage records + mean / time gradient) of several views in one pass over the coefficients
+	hipError_t launch_sh_bwd_batch(int nviews, const fdgs_scene* const* views, const fdgs_backward_in* const* ins,
+	                               const fdgs_backward_out* const* outs, hipStream_t stream);
 
 	// once per optimizer step: dL_dsh from the staged per-view records of the deferred SH backward (sh_bwd.hip)
 	hipError_t launch_sh_flush(int P, int D, int D_t, int M, int gaussian_dim, int force_sh_3d, int analytic, int nviews,

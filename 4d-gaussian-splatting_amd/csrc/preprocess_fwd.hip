@@ -449,6 +449,115 @@ namespace fdgs
 		return hipGetLastError();
 	}
 
+	// ------------------------------------------------------------------------------------------------
+	// SH colours of SEVERAL views in one pass over the coefficients (fdgs_preprocess_batch).
+	// Within one optimizer step the parameters are constant, and the 12 M bytes of SH coefficients per Gaussian are the bulk of
+	// what the preprocess reads (173 of ~200 MB per view at C3): the views' geometry runs per view (PART 1 above), their
+	// colours here -- every coefficient block is staged through LDS ONCE and evaluated for each view's direction and timestamp.
+	// Same device functions, same order of operations as PART 2: colours and clamp bits are bit-identical to the per-view path.
+	// ------------------------------------------------------------------------------------------------
+	constexpr int COLOUR_BATCH_MAX = 8;
+	struct ColourBatchArgs
+	{
+		int P, D, D_t, M, nviews;
+		const float *means3D, *shs, *ts;
+		float time_duration;
+		int gaussian_dim, force_sh_3d, sh_vec_ok;
+		struct View
+		{
+			const float* campos; float timestamp;
+			const int32_t* radii;       // of the view's geometry launch: colour only where radius > 0
+			float4* records; uint8_t* clamped;
+		} v[COLOUR_BATCH_MAX];
+	};
+
+	__global__ void __launch_bounds__(256) colour_batch_kernel(const ColourBatchArgs a)
+	{
+		__shared__ float s_sh[256 / WAVE][WAVE * SH_STRIDE];
+		// the views' running colours of this thread's Gaussian: [view * 3 + channel][thread] (the view loop is a real loop -- unrolled
+		// over 8 views the SH evaluation needs more registers than the file has -- so the per-view state lives here)
+		__shared__ float s_c[COLOUR_BATCH_MAX * 3][256];
+		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
+		const bool valid = tid_g < a.P;
+		const int idx = valid ? tid_g : a.P - 1;   // every lane stays: the SH blocks are staged cooperatively per wave
+		const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+		float* tile = s_sh[wave];
+		const float* row = tile + lane * SH_STRIDE;
+		const int g0 = blockIdx.x * blockDim.x + wave * WAVE;
+		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
+		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
+		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+		const float3 p_in = ld3(a.means3D, idx);   // Q4: the forward view direction uses the UN-shifted input mean (forward.cu:480-482)
+		const float t_in = (!sh3d) ? a.ts[idx] : 0.f;
+
+		bool any = false;
+#pragma unroll 1
+		for (int v = 0; v < a.nviews; v++) any = any || (valid && a.v[v].radii[idx] > 0);
+		const unsigned long long amask = __ballot(any);   // rows of Gaussians no view kept are never fetched
+		for (int blk = 0; blk < nblocks; blk++)
+		{
+			stage_sh_block(tile, a.shs, g0, a.P, a.M, 16 * blk, blk == 0 ? ncoef0 : 16, amask, lane, a.sh_vec_ok != 0);
+			__syncthreads();
+#pragma unroll 1
+			for (int v = 0; v < a.nviews; v++)
+			{
+				if (!(valid && a.v[v].radii[idx] > 0)) continue;
+				const float* cp = a.v[v].campos;
+				float3 dir = sub3(p_in, make_float3(cp[0], cp[1], cp[2]));
+				const float len = sqrtf(dot3(dir.x, dir.y, dir.z, dir.x, dir.y, dir.z));
+				dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+				float l[16];
+				if (!sh3d) sh_basis_4d(a.D, dir.x, dir.y, dir.z, l);
+				float3 c;
+				if (blk == 0) c = sh3d ? sh_color_3d(a.D, row, dir) : sh4d_block0(a.D, l, row);
+				else
+				{
+					const float dir_t = t_in - a.v[v].timestamp;
+					const float tk = (blk == 1) ? (float)cos(2 * REF_PI * dir_t / a.time_duration)
+					                            : (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+					c = make_float3(s_c[3 * v][threadIdx.x], s_c[3 * v + 1][threadIdx.x], s_c[3 * v + 2][threadIdx.x]);
+					c = add3(c, scl3(tk, sh_weighted(l, row, 0, 15, 0)));
+				}
+				if (blk == nblocks - 1)
+				{
+					if (!sh3d) c = make_float3(c.x + 0.5f, c.y + 0.5f, c.z + 0.5f); // sh_color_3d already added it
+					float* rec = reinterpret_cast<float*>(a.v[v].records + 3 * (size_t)idx);
+					rec[6] = fmaxf(c.x, 0.0f); rec[7] = fmaxf(c.y, 0.0f); rec[8] = fmaxf(c.z, 0.0f);
+					a.v[v].clamped[idx] = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
+				}
+				else { s_c[3 * v][threadIdx.x] = c.x; s_c[3 * v + 1][threadIdx.x] = c.y; s_c[3 * v + 2][threadIdx.x] = c.z; }
+			}
+			__syncthreads();
+		}
+	}
+
+	// views[v] / geoms[v]: the scene and the geometry buffer of view v; all views share P, M, degrees and the Gaussian tensors
+	hipError_t launch_colour_batch(int nviews, const fdgs_scene* const* views, const fdgs_forward_out* const* outs, char* const* geoms,
+	                               hipStream_t stream)
+	{
+		const fdgs_scene& s = *views[0];
+		if (s.P <= 0 || s.shs == nullptr) return hipSuccess;
+		const GeomLayout L = geom_layout(s.P);
+		for (int v0 = 0; v0 < nviews; v0 += COLOUR_BATCH_MAX)
+		{
+			ColourBatchArgs a;
+			a.P = s.P; a.D = s.D; a.D_t = s.D_t; a.M = s.M; a.nviews = min(COLOUR_BATCH_MAX, nviews - v0);
+			a.means3D = s.means3D; a.shs = s.shs; a.ts = s.ts; a.time_duration = s.time_duration;
+			a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d;
+			a.sh_vec_ok = ((reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
+			for (int v = 0; v < COLOUR_BATCH_MAX; v++)
+			{
+				const int w = min(v0 + v, nviews - 1);
+				a.v[v].campos = views[w]->campos; a.v[v].timestamp = views[w]->timestamp;
+				a.v[v].radii = outs[w]->radii;
+				a.v[v].records = reinterpret_cast<float4*>(geoms[w] + L.records);
+				a.v[v].clamped = reinterpret_cast<uint8_t*>(geoms[w] + L.clamped);
+			}
+			hipLaunchKernelGGL(colour_batch_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		}
+		return hipGetLastError();
+	}
+
 	// checkFrustum (rasterizer_impl.cu:54-67)
 	__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm, uint8_t* present)
 	{

@@ -371,6 +371,234 @@ namespace fdgs
 	}
 
 	// ------------------------------------------------------------------------------------------------
+	// SH backward of SEVERAL views in one pass over the coefficients (fdgs_sh_backward_batch; deferred mode only).
+	// What a view's SH backward has to read is the Gaussian's coefficient row (12 M bytes) -- the same row for every view of an
+	// optimizer step.  Here a wave scans 64 consecutive Gaussians, ballot-compacts those that carry a colour gradient in ANY
+	// view, and takes them 32 at a time: their WHOLE rows (the prefix the active degrees use) are staged once through a
+	// wave-private LDS tile with linear float4 loads, and lane = (Gaussian, view parity) evaluates its Gaussian for the views
+	// v = parity, parity + 2, ...: per view the 8 staged numbers for the flush (dL_dRGB, direction, the two cosine factors) and
+	// the mean / time gradient in words 12..15 of the view's accumulator record.  Same arithmetic, operation by operation, as
+	// sh_bwd_kernel<true> run view by view (tests compare them bit for bit).
+	// ------------------------------------------------------------------------------------------------
+	constexpr int SBB_MAX = 8;        // views per launch
+	constexpr int SBB_ROWS = 32;
+	constexpr int SBB_SPAN = 64;
+	constexpr int SBB_ACT = 144;      // floats of the three coefficient blocks that can be active
+	constexpr int SBB_STRIDE = SBB_ACT + 1;
+	struct ShBwdBatchArgs
+	{
+		int P, D, D_t, M, nviews;
+		const float *shs, *ts;
+		float time_duration;
+		int gaussian_dim, force_sh_3d, vec_ok, analytic;
+		struct View
+		{
+			const float* campos; float timestamp;
+			const int32_t* radii; const float* means; const uint8_t* clamped;
+			float* gacc; float4* stage;
+		} v[SBB_MAX];
+	};
+
+	__device__ __forceinline__ float3 colour_gradient_of(const float* gacc, const uint8_t* clamped, int idx)
+	{
+		const float4 w = *reinterpret_cast<const float4*>(gacc + (size_t)idx * GRAD_ACC_WORDS);
+		float3 dRGB = make_float3(w.x, w.y, w.z);
+		const uint8_t cl = clamped[idx];
+		if (cl & 1) dRGB.x = 0.f;
+		if (cl & 2) dRGB.y = 0.f;
+		if (cl & 4) dRGB.z = 0.f;
+		return dRGB;
+	}
+
+	__global__ void __launch_bounds__(WAVE) sh_bwd_batch_kernel(const ShBwdBatchArgs a)
+	{
+		__shared__ float tile[SBB_ROWS * SBB_STRIDE];
+		__shared__ uint32_t s_list[SBB_SPAN];
+		const int lane = threadIdx.x;
+		const int g0 = blockIdx.x * SBB_SPAN;
+		const int row_floats = 3 * a.M;
+		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
+		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
+		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
+		const int act = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);   // floats of a row the active degrees read
+		const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+		// ---- which Gaussians of the span carry a colour gradient in some view; the others get their zero stage records ----
+		int n = 0;
+		{
+			const int idx = g0 + lane;
+			const bool valid = idx < a.P;
+			bool any = false;
+#pragma unroll 1
+			for (int v = 0; v < a.nviews; v++)
+			{
+				bool live = false;
+				if (valid && a.v[v].radii[idx] > 0)
+				{
+					const float3 d = colour_gradient_of(a.v[v].gacc, a.v[v].clamped, idx);
+					live = d.x != 0.f || d.y != 0.f || d.z != 0.f;
+				}
+				if (valid && !live) a.v[v].stage[2 * (size_t)idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+				any = any || live;
+			}
+			const unsigned long long m = __ballot(any);
+			if (any) s_list[__popcll(m & lt_mask)] = (uint32_t)lane;
+			n = __popcll(m);
+		}
+		__builtin_amdgcn_wave_barrier();
+
+		const int g = lane & (SBB_ROWS - 1), vpar = lane >> 5;
+		for (int r0 = 0; r0 < n; r0 += SBB_ROWS)
+		{
+			const int nrows = min(SBB_ROWS, n - r0);
+			// ---- whole rows into the tile ----
+			if (a.vec_ok && (act & 3) == 0)
+			{
+				const int RC = act / 4, total = nrows * RC;
+				const int dg = WAVE / RC, dq = WAVE - dg * RC;
+				int cg = lane / RC, cq = lane - cg * RC;
+				for (int c0 = 0; c0 < total; c0 += 6 * WAVE)
+				{
+					float4 val[6];
+					int og[6], oq[6];
+#pragma unroll
+					for (int i = 0; i < 6; i++)
+					{
+						og[i] = cg; oq[i] = cq;
+						cg += dg; cq += dq;
+						if (cq >= RC) { cq -= RC; cg++; }
+						if (c0 + i * WAVE + lane >= total) og[i] = -1;
+						else val[i] = *reinterpret_cast<const float4*>(a.shs + (size_t)(g0 + (int)s_list[r0 + og[i]]) * row_floats + 4 * oq[i]);
+					}
+#pragma unroll
+					for (int i = 0; i < 6; i++)
+					{
+						if (og[i] < 0) continue;
+						float* d = tile + og[i] * SBB_STRIDE + 4 * oq[i];
+						d[0] = val[i].x; d[1] = val[i].y; d[2] = val[i].z; d[3] = val[i].w;
+					}
+				}
+			}
+			else
+			{
+				const int total = nrows * act;
+				const int dg = WAVE / act, dpos = WAVE - dg * act;
+				int cg = lane / act, pos = lane - cg * act;
+				for (int e = lane; e < total; e += WAVE)
+				{
+					tile[cg * SBB_STRIDE + pos] = a.shs[(size_t)(g0 + (int)s_list[r0 + cg]) * row_floats + pos];
+					cg += dg; pos += dpos;
+					if (pos >= act) { pos -= act; cg++; }
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+
+			// ---- lane = (row g, view parity): the views v = vpar, vpar + 2, ... of Gaussian list[r0 + g] ----
+			if (g < nrows)
+			{
+				const int idx = g0 + (int)s_list[r0 + g];
+				const float* row = tile + g * SBB_STRIDE;
+				const float t_in = sh3d ? 0.f : a.ts[idx];
+#pragma unroll 1
+				for (int v = vpar; v < a.nviews; v += 2)
+				{
+					if (!(a.v[v].radii[idx] > 0)) continue;
+					const float3 dRGB = colour_gradient_of(a.v[v].gacc, a.v[v].clamped, idx);
+					if (dRGB.x == 0.f && dRGB.y == 0.f && dRGB.z == 0.f) continue;
+					const float* cp = a.v[v].campos;
+					const float* mp = a.v[v].means + 3 * (size_t)idx;
+					const float3 dir_orig = make_float3(mp[0] - cp[0], mp[1] - cp[1], mp[2] - cp[2]); // Q4: shifted mean
+					const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+					const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+					const float dir_t = sh3d ? 0.f : t_in - a.v[v].timestamp;
+					float l[16], dX[16], dY[16], dZ[16];
+					sh_tables(a.D, dir.x, dir.y, dir.z, !sh3d, l, dX, dY, dZ);
+					float3 gx = make_float3(0.f, 0.f, 0.f), gy = gx, gz = gx, gt = gx;
+					float tk_stage[2] = { 0.f, 0.f };
+					for (int blk = 0; blk < nblocks; blk++)
+					{
+						const int nk = (blk == 0) ? ncoef0 : 16;
+						const float* brow = row + 48 * blk;
+						float tk = 1.f, dtk_dt = 0.f;
+						if (blk == 1)
+						{
+							tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
+							dtk_dt = (float)(sin(2 * REF_PI * dir_t / a.time_duration) * 2 * REF_PI / a.time_duration); // Q2
+						}
+						else if (blk == 2)
+						{
+							tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
+							dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
+						}
+						if (a.analytic) dtk_dt = -dtk_dt;
+						if (blk == 1) tk_stage[0] = tk;
+						if (blk == 2) tk_stage[1] = tk;
+						float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
+#pragma unroll
+						for (int k = 0; k < 16; k++)
+						{
+							if (k >= nk) break;
+							const float3 sv = s_ld3(brow, k);
+							st = s_add(st, s_scl(l[k], sv));
+							sx = s_add(sx, s_scl(dX[k], sv));
+							sy = s_add(sy, s_scl(dY[k], sv));
+							sz = s_add(sz, s_scl(dZ[k], sv));
+						}
+						if (blk == 0) { gx = sx; gy = sy; gz = sz; }
+						else
+						{
+							gx = s_add(gx, s_scl(tk, sx)); gy = s_add(gy, s_scl(tk, sy)); gz = s_add(gz, s_scl(tk, sz));
+							gt = a.analytic ? s_add(gt, s_scl(dtk_dt, st)) : s_scl(dtk_dt, st); // Q3: overwrite, not accumulate
+						}
+					}
+					a.v[v].stage[2 * (size_t)idx] = make_float4(dRGB.x, dRGB.y, dRGB.z, tk_stage[0]);
+					a.v[v].stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, tk_stage[1]);
+					float4 o;
+					const float3 ddir = make_float3(s_dot(gx, dRGB), s_dot(gy, dRGB), s_dot(gz, dRGB));
+					// dnormvdv, auxiliary.h:108-118
+					const float3 w = dir_orig;
+					const float sum2 = w.x * w.x + w.y * w.y + w.z * w.z;
+					const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+					o.x = ((+sum2 - w.x * w.x) * ddir.x - w.y * w.x * ddir.y - w.z * w.x * ddir.z) * invsum32;
+					o.y = (-w.x * w.y * ddir.x + (sum2 - w.y * w.y) * ddir.y - w.z * w.y * ddir.z) * invsum32;
+					o.z = (-w.x * w.z * ddir.x - w.y * w.z * ddir.y + (sum2 - w.z * w.z) * ddir.z) * invsum32;
+					o.w = sh3d ? 0.f : s_dot(gt, dRGB);
+					reinterpret_cast<float4*>(a.v[v].gacc + (size_t)idx * GRAD_ACC_WORDS)[3] = o;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+
+	// views / ins / outs / geoms of the batch: all views share P, M, the degrees and the Gaussian tensors; outs[v]->sh_stage and
+	// outs[v]->grad_accum are the view's own
+	hipError_t launch_sh_bwd_batch(int nviews, const fdgs_scene* const* views, const fdgs_backward_in* const* ins,
+	                               const fdgs_backward_out* const* outs, hipStream_t stream)
+	{
+		const fdgs_scene& s = *views[0];
+		if (s.shs == nullptr || s.M <= 0 || s.P <= 0) return hipSuccess;
+		const GeomLayout L = geom_layout(s.P);
+		for (int v0 = 0; v0 < nviews; v0 += SBB_MAX)
+		{
+			ShBwdBatchArgs a;
+			a.P = s.P; a.D = s.D; a.D_t = s.D_t; a.M = s.M; a.nviews = min(SBB_MAX, nviews - v0);
+			a.shs = s.shs; a.ts = s.ts; a.time_duration = s.time_duration;
+			a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.analytic = s.analytic_sh_grad;
+			a.vec_ok = ((reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
+			for (int v = 0; v < SBB_MAX; v++)
+			{
+				const int w = min(v0 + v, nviews - 1);
+				a.v[v].campos = views[w]->campos; a.v[v].timestamp = views[w]->timestamp;
+				a.v[v].radii = ins[w]->radii; a.v[v].means = ins[w]->out_means3D;
+				a.v[v].clamped = reinterpret_cast<const uint8_t*>(reinterpret_cast<const char*>(ins[w]->geom_buffer) + L.clamped);
+				a.v[v].gacc = outs[w]->grad_accum; a.v[v].stage = reinterpret_cast<float4*>(outs[w]->sh_stage);
+			}
+			hipLaunchKernelGGL(sh_bwd_batch_kernel, dim3(div_up(s.P, SBB_SPAN)), dim3(WAVE), 0, stream, a);
+		}
+		return hipGetLastError();
+	}
+
+	// ------------------------------------------------------------------------------------------------
 	// Deferred SH gradient (gradient accumulation over the views of one optimizer step).
 	// dL_dsh of a view is basis(view direction) x time factor (x) dL_dRGB: M x 3 floats written (or read-modified-written,
 	// from the second view on) per Gaussian and view, although the view only contributes 8 numbers.  In deferred mode

@@ -22,26 +22,43 @@ import torch
 from .gaussian_renderer.diff_gaussian_rasterization import GaussianRasterizationSettings, _C, _is_given
 
 
-def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
-                split_colour=False):
-    """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple."""
+def _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var):
     e = torch.Tensor([])
-    args = (rs.bg, means3D, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
+    return (rs.bg, means3D, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
             rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
             rs.image_height, rs.image_width, sh, rs.sh_degree, rs.sh_degree_t, rs.campos, rs.timestamp,
             rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, rs.prefiltered, rs.debug)
-    return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour)
+
+
+def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
+                split_colour=False, preprocessed=None):
+    """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple.
+    ``preprocessed``: the view's handle from ``raw_preprocess_batch``."""
+    args = _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
+    return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour, preprocessed=preprocessed)
+
+
+def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var):
+    """View-batched preprocess on RAW parameters (fdgs_preprocess_batch): ``settings`` = the views' raster settings (the views of
+    one optimizer step share every parameter tensor).  One handle per view for ``raw_forward(..., preprocessed=handle)``."""
+    views = [_raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
+             for rs in settings]
+    return _C.preprocess_batch(views, raw_params=True)
 
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
                  prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=None, after_sh=None,
-                 sh_stage=None):
-    """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple."""
+                 sh_stage=None, begin_only=False):
+    """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple.
+    ``begin_only``: only the blend backward (``_C.backward_begin``): returns the pending call for ``_C.sh_backward_batch`` /
+    ``_C.backward_finish``."""
     e = torch.Tensor([])
     args = (rs.bg, means3D, out_means3D, radii, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
             rotation_r_raw, rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
             rs.tanfovy, g_color, g_depth, g_alpha, g_flow, sh, rs.sh_degree, rs.sh_degree_t, rs.campos,
             rs.timestamp, rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, geom, R, binb, img, rs.debug)
+    if begin_only:
+        return _C.backward_begin(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum, sh_stage=sh_stage)
     return _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum,
                                            after_sh=after_sh, sh_stage=sh_stage)
 

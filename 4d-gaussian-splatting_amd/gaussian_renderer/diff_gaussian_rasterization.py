@@ -51,9 +51,14 @@ class _Scratch:
     def __init__(self, device):
         self.device = device
         self.buf = {}
+        self.reuse = False   # a view preprocessed by fdgs_preprocess_batch: its forward call gets the same geometry / image buffers
         self.callback = _capi.ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, which, nbytes):
+        if self.reuse and int(which) in (_capi.FDGS_BUF_GEOMETRY, _capi.FDGS_BUF_IMAGE):
+            t = self.buf.get(int(which))
+            if t is not None and t.numel() >= int(nbytes):
+                return t.data_ptr()
         try:
             t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
         except Exception:  # out of memory: report NULL to the C side, which returns FDGS_ERR_ALLOC
@@ -112,7 +117,7 @@ class _NativeRasterizer:
     def rasterize_gaussians(self, bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
                             scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
-                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False):
+                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False, preprocessed=None):
         """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49).
         Keyword-only extensions: ``raw_params``: the scale / opacity / rotation tensors are the model's raw
         parameters and the kernels apply the activations (fdgs_scene.raw_params); ``split_colour``: the SH colour evaluation
@@ -120,10 +125,15 @@ class _NativeRasterizer:
         if not means3D.is_cuda:
             raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
         dev = means3D.device
-        scene, keep = self._scene(bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
-                                  scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx,
-                                  tan_fovy, image_height, image_width, sh, degree, degree_t, campos, timestamp,
-                                  time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug, raw_params)
+        if preprocessed is not None:
+            # ``preprocessed``: this view's handle from preprocess_batch (same arguments): geometry and SH colours are already
+            # enqueued on this stream; the call continues with the tile binning and the blend
+            scene, keep = preprocessed["scene"], preprocessed["keep"]
+        else:
+            scene, keep = self._scene(bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
+                                      scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx,
+                                      tan_fovy, image_height, image_width, sh, degree, degree_t, campos, timestamp,
+                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, prefiltered, debug, raw_params)
         P, H, W = scene.P, scene.H, scene.W
         fo = dict(dtype=torch.float32, device=dev)
         # every output is fully written by the kernels: torch.empty, not torch.full (rasterize_points.cu:80-85)
@@ -131,12 +141,16 @@ class _NativeRasterizer:
         out_flow = torch.empty((2, H, W), **fo)
         out_depth = torch.empty((1, H, W), **fo)
         out_T = torch.empty((1, H, W), **fo)
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        out_means3D = torch.empty((P, 3), **fo)
-        covs_com = torch.empty((P, 6), **fo)  # owning, not a from_blob alias of the scratch (rasterize_points.cu:144-147)
+        if preprocessed is not None:
+            radii, out_means3D, covs_com, scratch = (preprocessed[k] for k in ("radii", "out_means3D", "covs_com", "scratch"))
+        else:
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            out_means3D = torch.empty((P, 3), **fo)
+            covs_com = torch.empty((P, 6), **fo)  # owning, not a from_blob alias of the scratch (rasterize_points.cu:144-147)
+            scratch = _Scratch(dev)
         out = _capi.FdgsForwardOut(out_color.data_ptr(), out_flow.data_ptr(), out_depth.data_ptr(), out_T.data_ptr(),
-                                   _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com), int(bool(split_colour)))
-        scratch = _Scratch(dev)
+                                   _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com),
+                                   int(preprocessed is not None), int(bool(split_colour)))
         R = C.c_int32(0)
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), scratch.callback, None,
@@ -146,13 +160,75 @@ class _NativeRasterizer:
         del keep
         return (int(R.value), out_color, out_flow, out_depth, out_T, radii, geom, binb, img, covs_com, out_means3D)
 
+    def preprocess_batch(self, views, *, raw_params=False):
+        """View-batched preprocess (fdgs_preprocess_batch): ``views`` = the 30-tuples of positional arguments of
+        ``rasterize_gaussians`` for the views of ONE optimizer step (same Gaussian tensors, own camera / timestamp).  The
+        geometry runs per view, the SH colours of all views in one pass over the coefficients.  Returns one handle per view;
+        ``rasterize_gaussians(*views[v], raw_params=..., preprocessed=handles[v])`` then completes view v on the same stream."""
+        dev = views[0][1].device
+        if not views[0][1].is_cuda:
+            raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
+        handles = []
+        for a in views:
+            scene, keep = self._scene(*a, raw_params)
+            P = scene.P
+            fo = dict(dtype=torch.float32, device=dev)
+            h = {"scene": scene, "keep": keep, "radii": torch.empty((P,), dtype=torch.int32, device=dev),
+                 "out_means3D": torch.empty((P, 3), **fo), "covs_com": torch.empty((P, 6), **fo), "scratch": _Scratch(dev)}
+            h["scratch"].reuse = True
+            h["out"] = _capi.FdgsForwardOut(None, None, None, None, _capi._ptr(h["radii"]), _capi._ptr(h["out_means3D"]),
+                                            _capi._ptr(h["covs_com"]), 0, 0)
+            handles.append(h)
+        B = len(handles)
+        scenes = (C.POINTER(_capi.FdgsScene) * B)(*[C.pointer(h["scene"]) for h in handles])
+        outs = (C.POINTER(_capi.FdgsForwardOut) * B)(*[C.pointer(h["out"]) for h in handles])
+        users = (C.c_void_p * B)(*[v + 1 for v in range(B)])
+        # one callback for the batch: the user word says which view's buffer is asked for
+        cb = _capi.ALLOC_FN(lambda user, which, nbytes: handles[int(user) - 1]["scratch"]._alloc(None, which, nbytes))
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_preprocess_batch(B, scenes, outs, cb, users, _capi.current_stream_handle(dev))
+        _capi._check(rc, "fdgs_preprocess_batch")
+        return handles
+
+    def sh_backward_batch(self, pendings):
+        """View-batched SH backward (fdgs_sh_backward_batch) of the views whose blend backward ``backward_begin`` has enqueued."""
+        B = len(pendings)
+        dev = pendings[0]["dev"]
+        scenes = (C.POINTER(_capi.FdgsScene) * B)(*[C.pointer(p["scene"]) for p in pendings])
+        ins = (C.POINTER(_capi.FdgsBackwardIn) * B)(*[C.pointer(p["bin"]) for p in pendings])
+        outs = (C.POINTER(_capi.FdgsBackwardOut) * B)(*[C.pointer(p["bout"]) for p in pendings])
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_sh_backward_batch(B, scenes, ins, outs, _capi.current_stream_handle(dev))
+        _capi._check(rc, "fdgs_sh_backward_batch")
+
+    def backward_begin(self, *args, **kw):
+        """The blend backward of one view only (fdgs_backward_out.stage_mask = 5); same arguments as
+        ``rasterize_gaussians_backward`` (``sh_stage`` and a ``grad_accum`` of the view's own are required).  Returns the pending
+        call for ``sh_backward_batch`` / ``backward_finish``."""
+        return self.rasterize_gaussians_backward(*args, _phase="begin", **kw)
+
+    def backward_finish(self, pending):
+        """The geometry backward (stage_mask = 2) of a view begun with ``backward_begin``, after ``sh_backward_batch``; returns the
+        binding's 12-tuple."""
+        dev = pending["dev"]
+        pending["bout"].stage_mask = 2
+        with torch.cuda.device(dev):
+            rc = _capi.lib.fdgs_rasterize_backward(C.byref(pending["scene"]), C.byref(pending["bin"]), C.byref(pending["bout"]),
+                                                   _capi.current_stream_handle(dev))
+        if rc != 0 and pending["clean"]:
+            pending["grad_accum"].zero_()
+        _capi._check(rc, "fdgs_rasterize_backward")
+        g = pending["g"]
+        return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
+                g["dL_dflows"], g["dL_dts"], g["dL_dscales"], g["dL_dscales_t"], g["dL_drotations"], g["dL_drotations_r"])
+
     def rasterize_gaussians_backward(self, bg, means3D, out_means3D, radii, colors, flows_2d, opacities, ts, scales,
                                      scales_t, rotations, rotations_r, scale_modifier, cov3D_precomp, prefilter_var,
                                      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
                                      imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False, grad_accum=None,
-                                     after_sh=None, sh_stage=None):
+                                     after_sh=None, sh_stage=None, _phase=None):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
@@ -215,6 +291,17 @@ class _NativeRasterizer:
         if sh_stage is not None and (sh_stage.numel() != P * 8 or sh_stage.dtype != torch.float32 or not sh_stage.is_contiguous()):
             raise RuntimeError("fdgs: sh_stage must be a contiguous float32 tensor with %d elements" % (P * 8))
         bout = _capi.FdgsBackwardOut(*ptrs, int(bool(accumulate)), _capi._ptr(g["grad_accum"]), clean, _capi._ptr(sh_stage), 0)
+        if _phase == "begin":
+            if sh_stage is None or grad_accum is None:
+                raise RuntimeError("fdgs: backward_begin needs sh_stage and a grad_accum of the view's own")
+            bout.stage_mask = 5   # blend backward only; the SH backward is left to sh_backward_batch
+            with torch.cuda.device(dev):
+                rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout), _capi.current_stream_handle(dev))
+            if rc != 0:
+                grad_accum.zero_()
+            _capi._check(rc, "fdgs_rasterize_backward")
+            return {"scene": scene, "keep": keep, "bin": bin_, "bout": bout, "g": g, "dev": dev, "clean": clean, "grad_accum": grad_accum,
+                    "alive": (gin, radii_c, om_c, geomBuffer, binningBuffer, imageBuffer, sh_stage)}
         with torch.cuda.device(dev):
             if after_sh is None:
                 rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),

@@ -18,7 +18,7 @@ from typing import List, Sequence
 import torch
 
 from . import _capi
-from .fused import raw_backward, raw_forward, raw_settings
+from .fused import raw_backward, raw_forward, raw_preprocess_batch, raw_settings
 from .gaussian_renderer import diff_gaussian_rasterization as _dgr
 from .loss import l1_ssim_grad, l1_ssim_loss
 from .train_host import allreduce_and_step, allreduce_sh_begin, gather_sh_stages_begin
@@ -26,7 +26,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_sh_stages
 
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
-                 fuse_sh_adam: bool = True, gather_max_views: int = 16, split_colour: bool = False):
+                 fuse_sh_adam: bool = True, gather_max_views: int = 16, split_colour: bool = False, batch_views: bool = False):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -38,6 +38,15 @@ class StepPipeline:
         # runs the fused update on all of them (train_host.gather_sh_stages_begin); beyond it the dense all-reduce is cheaper
         self.gather_max_views = int(gather_max_views)
         self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
+        # View batching (opt-in, B > 1): the SH coefficients -- 12 M bytes per Gaussian, most of what preprocess and SH backward
+        # read -- are the same for every view of the step.  The views' geometry still runs per view, but their SH colours come
+        # from ONE pass over the coefficients before the first view's binning (fdgs_preprocess_batch), and their SH backward from
+        # ONE pass after the last view's blend backward (fdgs_sh_backward_batch); the views' geometry backward follows it.
+        # Measured at C3, 4 views per step: 120 us less kernel time per step, 3.66 -> 3.56 ms on one stream; with the two
+        # streams it is a wash (3.04 -> 3.04-3.10 ms): the batched head and tail of the step have nothing to overlap with.  Off by
+        # default.
+        self.batch_views = bool(batch_views)
+        self._gacc_b = None   # [B, P, 16] persistent always-zero accumulators, one per view (the batched SH backward reads all of them)
         dev = model.flat.device
         self.dev = dev
         # (Tried and dropped, with measurements on MI355X: a high-priority F stream and a CU-masked B stream change
@@ -82,6 +91,8 @@ class StepPipeline:
         sh_handle = []
         sh_gather = []     # gather: (work, stages of all ranks)
         sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
+        if self.batch_views and B > 1 and defer_sh:
+            return self._step_batched(cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped)
         for b in range(B):
             with torch.cuda.stream(self.sF):
                 rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
@@ -126,6 +137,19 @@ class StepPipeline:
             results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow,
                             "viewspace_grad": grads[0], "num_rendered": R})
             losses.append(loss)
+        self._optimizer_tail(rs, fuse, gather, sh_handle, sh_gather, sh_stepped)
+        main.wait_stream(self.sB)
+        main.wait_stream(self.sF)
+        self.sF.wait_stream(self.sB)
+        # The returned tensors live in the F / B streams' allocator pools.  `main` has waited for both streams, and the
+        # next step() makes both streams wait for `main` first, so they are safe to read on `main` until then
+        # (no record_stream: it would defer every free by an event query and grow the pools).
+        del keep
+        return results, losses
+
+    def _optimizer_tail(self, rs, fuse, gather, sh_handle, sh_gather, sh_stepped):
+        """Exchange (several ranks) + optimizer step on stream B, after the last view's backward."""
+        m = self.model
         with torch.cuda.stream(self.sB):
             # the losses were scaled by 1 / (B * world): SUM = mean; Adam on chunk k overlaps the all-reduce of chunk k+1
             if fuse:
@@ -153,11 +177,66 @@ class StepPipeline:
                 self.opt.step_range(0, feat if ok else m.flat.numel())
             else:
                 allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None)
+
+    def _after_sh(self, rs, fuse, gather, defer_sh, sh_handle, sh_gather, sh_stepped):
+        """What starts as soon as the SH stages of the step are complete (stream B is current): the fused SH update on the idle F
+        stream (one rank), the exchange of the stages, or the flush + the all-reduce of the SH part of the bucket (several ranks)."""
+        m = self.model
+        if fuse and self.sB is not self.sF:
+            done = torch.cuda.Event()
+            done.record(self.sB)
+            with torch.cuda.stream(self.sF):
+                self.sF.wait_event(done)
+                self.opt.step_count += 1
+                sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
+        elif gather:
+            sh_gather.append(gather_sh_stages_begin(self._sh_stage, self.world))
+        elif (defer_sh and not fuse) or self.world > 1:
+            if defer_sh:
+                _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
+                               rs.force_sh_3d, _dgr.analytic_sh_gradients())
+            if self.world > 1:
+                sh_handle.append(allreduce_sh_begin(m, self.world))
+
+    def _step_batched(self, cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped):
+        """step() with the views' SH work batched (see __init__): stream F: geometry of every view, ONE colour pass, then per view
+        binning + blend; stream B: per view loss + blend backward, then ONE SH backward pass, the views' geometry backward, the
+        optimizer.  Same arithmetic per view as the unbatched step (forward bit-identical; tests/test_gpu_api.py)."""
+        B, m = len(cams), self.model
+        if self._gacc_b is None or self._gacc_b.shape[0] != B or self._gacc_b.shape[1] != m.P:
+            with torch.cuda.stream(self.sB):
+                self._gacc_b = torch.zeros((B, m.P, 16), dtype=torch.float32, device=self.dev)
+        results, losses, keep, pend, loss_handles = [], [], [], [], []
+        with torch.cuda.stream(self.sF):
+            sets = [raw_settings(c, m, pipe, bg, scaling_modifier) for c in cams]
+            (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = sets[0][1]
+            handles = raw_preprocess_batch([s[0] for s in sets], xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var)
+        for b in range(B):
+            rs = sets[b][0]
+            with torch.cuda.stream(self.sF):
+                (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
+                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b])
+                ev = torch.cuda.Event()
+                ev.record(self.sF)
+            with torch.cuda.stream(self.sB):
+                self.sB.wait_event(ev)
+                g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
+                pend.append(raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r,
+                                         prefilter_var, geom, R, binb, img, g_color, None, None, None, self.sink, b > 0,
+                                         grad_accum=self._gacc_b[b], sh_stage=self._sh_stage[b], begin_only=True))
+            loss_handles.append(loss_handle)
+            keep.append((geom, binb, img, out_means3D, g_color, T))
+            results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow, "num_rendered": R})
+        with torch.cuda.stream(self.sB):
+            _dgr._C.sh_backward_batch(pend)
+            self._after_sh(rs, fuse, gather, True, sh_handle, sh_gather, sh_stepped)
+            for b in range(B):
+                grads = _dgr._C.backward_finish(pend[b])
+                results[b]["viewspace_grad"] = grads[0]
+                losses.append(l1_ssim_loss(loss_handles[b]))
+        self._optimizer_tail(rs, fuse, gather, sh_handle, sh_gather, sh_stepped)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)
         self.sF.wait_stream(self.sB)
-        # The returned tensors live in the F / B streams' allocator pools.  `main` has waited for both streams, and the
-        # next step() makes both streams wait for `main` first, so they are safe to read on `main` until then
-        # (no record_stream: it would defer every free by an event query and grow the pools).
-        del keep
+        del keep, pend, handles
         return results, losses

@@ -90,6 +90,9 @@ def parse_args():
                     help="fused kernels driven through autograd (render_raw + fused_l1_ssim + backward()) on one stream, "
                          "instead of the explicit two-stream step pipeline (fdgs/pipeline.py)")
     ap.add_argument("--no-overlap", action="store_true", help="step pipeline on a single stream (A/B for the overlap)")
+    ap.add_argument("--batch-views", action="store_true",
+                    help="A/B: SH colours and SH backward of the step's views in one pass over the coefficients each "
+                         "(fdgs_preprocess_batch / fdgs_sh_backward_batch): fewer bytes, but a serial head and tail of the step")
     ap.add_argument("--split-colour", choices=("forward", "all", "off"), default="forward",
                     help="fdgs_forward_out.split_colour (SH colours on the library's second stream next to the binning): in the "
                          "forward-only loop (default), also in the training step, or nowhere")
@@ -318,7 +321,8 @@ def main():
     if use_pipeline:
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
-                                gather_max_views=0 if args.dense_sh_exchange else 16, split_colour=args.split_colour == "all")
+                                gather_max_views=0 if args.dense_sh_exchange else 16, split_colour=args.split_colour == "all",
+                                batch_views=args.batch_views)
 
     def step():
         if use_pipeline:
@@ -350,7 +354,7 @@ def main():
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.
     if use_pipeline:
         stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
-                                  gather_max_views=0 if args.dense_sh_exchange else 16)
+                                  gather_max_views=0 if args.dense_sh_exchange else 16, batch_views=args.batch_views)
         stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)  # noqa: E731
     else:
         stage_step = step

@@ -133,6 +133,10 @@ typedef struct fdgs_forward_out
 	float* out_means3D;   /* [P,3]    means3D, shifted by the conditional mean where rot_4d */
 	float* covs_com;      /* [P,6] or NULL: owning copy of the computed 3D covariances
 	                         (zero for culled Gaussians; the reference returns uninitialised memory there) */
+	int32_t preprocessed; /* 0: the call runs the whole forward.  1: the per-Gaussian preprocess of this view was enqueued on the same
+	                         stream by fdgs_preprocess_batch (which obtained the view's geometry and image buffers from the
+	                         allocator): the call asks the allocator for the same two buffers again -- the allocator must answer
+	                         with the SAME pointers -- and continues with the tile binning and the blend */
 	int32_t split_colour; /* 0: one preprocess launch.  1: geometry first, the SH -> RGB evaluation (the bulk of the preprocess'
 	                         memory traffic, which only the blend needs) on an internal second stream next to the tile binning
 	                         (events in and out): shortens the forward's critical path by ~30 us at C3 for forward-only
@@ -194,7 +198,10 @@ typedef struct fdgs_backward_out
 	int32_t stage_mask;       /* 0 (or 3): the whole backward.  1: blend backward + SH backward only -- dL_dsh is final when
 	                             they have run; 2: the geometry backward only (must follow a call with 1 on the same
 	                             stream, same arguments).  Lets a data-parallel caller start the all-reduce of the SH
-	                             gradients (88 % of the bytes at M = 48) while the geometry backward still runs. */
+	                             gradients (88 % of the bytes at M = 48) while the geometry backward still runs.
+	                             + 4 (5 = blend backward only): the SH backward of this view is left to fdgs_sh_backward_batch, which
+	                             does it for all views of the optimizer step in one pass over the coefficients; the view's
+	                             geometry backward (2) follows after that call.  Needs sh_stage and a grad_accum of the view's own. */
 } fdgs_backward_out;
 
 /* Forward pass: preprocess -> tile count -> tile scan -> tile scatter -> per-tile local sort (+ ranges) -> per-tile
@@ -210,6 +217,24 @@ int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
  * calling thread's previous call; 0: it always waits and asks the allocator for exactly fdgs_binning_bytes(num_rendered)
  * (+ the long-list scratch), as the reference does.  Process-wide. */
 void fdgs_set_run_ahead(int32_t enable);
+
+/* View-batched preprocess (the views of ONE optimizer step: same Gaussian tensors, same P / M / degrees / flags; cameras and
+ * timestamps differ).  The 12 M bytes of SH coefficients per Gaussian are most of what the preprocess reads, and they are
+ * the same for every view: the geometry part runs per view, the SH colours of all views in ONE pass over the coefficients
+ * (bit-identical to the per-view forward).  For each view v the call obtains the geometry and the image buffer through
+ * alloc(alloc_users[v], ...) and fills outs[v]->radii / out_means3D / covs_com; the views' forwards are then completed one by
+ * one with fdgs_rasterize_forward(scenes[v], outs[v] with preprocessed = 1, alloc, alloc_users[v], the same stream, ...).
+ * The reference has no counterpart (train.py:104-166 renders the views of a batch strictly one after the other). */
+int fdgs_preprocess_batch(int32_t num_views, const fdgs_scene* const* scenes, const fdgs_forward_out* const* outs,
+                          fdgs_alloc_fn alloc, void* const* alloc_users, void* stream);
+
+/* View-batched SH backward (deferred mode), the counterpart of fdgs_preprocess_batch: after the blend backward of every
+ * view (fdgs_rasterize_backward with stage_mask = 5, a grad_accum and an sh_stage of the view's own), ONE pass over the SH
+ * coefficients produces every view's stage record and its mean / time gradient (words 12..15 of the view's accumulator
+ * records); the views' geometry backward (stage_mask = 2) and fdgs_sh_flush / fdgs_adam_step_sh follow.  Bit-identical to the
+ * per-view SH backward.  ins[v] / outs[v]: the structs of the views' backward calls. */
+int fdgs_sh_backward_batch(int32_t num_views, const fdgs_scene* const* scenes, const fdgs_backward_in* const* ins,
+                           const fdgs_backward_out* const* outs, void* stream);
 
 /* Introspection for tests: how the forward calls of this process went -- counts3[0] scatter / sort / blend enqueued before
  * num_rendered was back and kept, [1] enqueued ahead but sorted again (longer tile lists than the previous call suggested),

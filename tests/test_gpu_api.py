@@ -345,7 +345,8 @@ def test_sh_adam_fused_is_flush_plus_adam(gpu_device, D, D_t, M, sh3d, analytic)
 
 
 @pytest.mark.parametrize("overlap,fuse,B", [(True, True, 3), (False, True, 3), (True, False, 3), (True, True, 1), (True, False, 1)])
-def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B):
+@pytest.mark.parametrize("batch", [True, False], ids=["batched-sh", "per-view-sh"])
+def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B, batch):
     """fdgs.pipeline.StepPipeline (explicit forward / fused loss / backward on two HIP streams, no autograd) performs
     the same optimizer step as render_raw + fused_l1_ssim + backward() + Adam on one stream."""
     from fdgs import train_host
@@ -372,7 +373,7 @@ def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B):
         oa.step()
 
     mp = train_host.GaussianParams(scene, gpu_device)
-    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap, fuse_sh_adam=fuse)
+    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap, fuse_sh_adam=fuse, batch_views=batch)
     got_losses = []
     for _ in range(2):
         results, losses = sp.step(cams, gts, pipe, bg)
@@ -390,3 +391,114 @@ def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B):
     # around zero (more of them with a single view) its sign, hence 2 lr per step, differs between two runs
     perr = (mp.flat - ma.flat).abs()
     assert (perr > 2e-3).float().mean().item() <= 2e-3 and perr.max().item() <= 0.25, ((perr > 2e-3).float().mean().item(), perr.max().item())
+
+
+@pytest.mark.parametrize("cfg", [synth.SceneConfig("b4", 20000, 320, 240, 3, 2, 0.03, 10.0, True, 4, False),
+                                 synth.SceneConfig("b3", 9000, 208, 160, 2, 0, 0.03, 1.0, False, 3, True),
+                                 synth.SceneConfig("b0", 5000, 160, 128, 0, 0, 0.03, 1.0, True, 4, True)], ids=["4d-sh", "3d-sh", "deg0"])
+def test_preprocess_batch_forward_is_bit_identical(cfg, gpu_device):
+    """fdgs_preprocess_batch: the geometry of every view per view, the SH colours of all views in ONE pass over the coefficients;
+    every forward output and every introspected buffer of every view equals the per-view forward bit for bit (same arithmetic in
+    the same order).  9 views: two launches of the colour kernel (8 views per launch)."""
+    from fdgs import train_host
+    from fdgs.fused import raw_forward, raw_preprocess_batch, raw_settings
+    from util import collect_forward
+    scene = synth.make_scene(cfg, seed=31)
+    model = train_host.GaussianParams(scene, gpu_device)
+    pipe = train_host.PipelineFlags()
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    nv = 9
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / nv * scene["time_duration"]) for b in range(nv)]
+    for b, c in enumerate(cams):   # different cameras too: shift the view and camera centre a little per view
+        wv = c.world_view_transform.clone()
+        wv[3, 0] += 0.03 * b
+        wv[3, 1] -= 0.02 * b
+        c.world_view_transform = wv
+        c.full_proj_transform = wv @ (torch.linalg.inv(scene["world_view_transform"].to(gpu_device)) @ scene["full_proj_transform"].to(gpu_device))
+        c.camera_center = torch.linalg.inv(wv)[3, :3].contiguous()
+    P, W, H = model.P, scene["W"], scene["H"]
+    sets = [raw_settings(c, model, pipe, bg) for c in cams]
+    tens = sets[0][1]
+    single = [collect_forward(raw_forward(rs, *tens), P, W, H) for rs, _ in sets]
+    handles = raw_preprocess_batch([rs for rs, _ in sets], *tens)
+    batched = [collect_forward(raw_forward(rs, *tens, preprocessed=handles[b]), P, W, H) for b, (rs, _) in enumerate(sets)]
+    for b in range(nv):
+        for key in ("R", "out_color", "out_flow", "out_depth", "out_T", "radii", "out_means3D", "covs_com", "n_contrib", "final_T", "point_list",
+                    "ranges", "rgb", "clamped_bits", "conic_opacity", "means2D", "rec_depth", "rec_flow", "depths", "cov3D", "tiles_touched"):
+            np.testing.assert_array_equal(single[b][key], batched[b][key], err_msg="view %d %s" % (b, key))
+    assert single[0]["R"] > 0 and (single[0]["rgb"] != 0).any()
+    assert not np.array_equal(single[0]["out_color"], single[nv - 1]["out_color"])   # the views do differ
+
+
+@pytest.mark.parametrize("cfg", [synth.SceneConfig("s4", 20000, 320, 240, 3, 2, 0.03, 10.0, True, 4, False),
+                                 synth.SceneConfig("s3", 9000, 208, 160, 2, 0, 0.03, 1.0, False, 3, True),
+                                 synth.SceneConfig("s1", 6000, 160, 128, 3, 1, 0.03, 2.0, True, 4, False)], ids=["4d-sh-t2", "3d-sh", "4d-sh-t1"])
+def test_sh_backward_batch_matches_per_view(cfg, gpu_device):
+    """fdgs_sh_backward_batch: blend backward per view (stage_mask 5), ONE SH backward pass for all views, geometry backward per
+    view -- against the per-view backward with the deferred SH gradient.  The two runs differ only in the order of the blend
+    backward's float atomics, so: stage records and every gradient equal to 1e-5 of their scale; where a view's dL_dRGB is exactly
+    zero (Gaussian not live) both leave a zero stage record."""
+    from fdgs import _capi, train_host
+    from fdgs.fused import raw_backward, raw_forward, raw_settings
+    from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C, analytic_sh_gradients
+    scene = synth.make_scene(cfg, seed=33)
+    model = train_host.GaussianParams(scene, gpu_device)
+    pipe = train_host.PipelineFlags()
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    nv = 5   # odd: the two view parities of the kernel get 3 and 2 views
+    P, W, H = model.P, scene["W"], scene["H"]
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / nv * scene["time_duration"]) for b in range(nv)]
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    ups = [(torch.randn(3, H, W, generator=gen) * 1e-2).to(gpu_device) for _ in range(nv)]
+    sets = [raw_settings(c, model, pipe, bg) for c in cams]
+    tens = sets[0][1]
+    (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = tens
+    fwd = [raw_forward(rs, *tens) for rs, _ in sets]
+
+    def run(batched):
+        sink = {k: torch.zeros_like(v) for k, v in model.grad_sink().items()}
+        stage = torch.full((nv, P, 8), float("nan"), device=gpu_device)
+        gacc = torch.zeros((nv, P, 16), device=gpu_device)
+        per_view, pend = [], []
+        for b, (rs, _) in enumerate(sets):
+            (R, color, flow, depth, T, radii, geom, binb, img, _covs, om) = fwd[b]
+            args = (rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img, ups[b], None, None, None,
+                    sink, b > 0)
+            if batched:
+                pend.append(raw_backward(*args, grad_accum=gacc[b], sh_stage=stage[b], begin_only=True))
+            else:
+                per_view.append(raw_backward(*args, grad_accum=gacc[b], sh_stage=stage[b]))
+        if batched:
+            _C.sh_backward_batch(pend)
+            per_view = [_C.backward_finish(p) for p in pend]
+        torch.cuda.synchronize()
+        assert float(gacc.abs().max()) == 0.0   # every view's accumulator is left all zero
+        dsh = torch.empty((P, model.M, 3), device=gpu_device)
+        _capi.sh_flush(stage, dsh, sets[0][0].sh_degree, sets[0][0].sh_degree_t, sets[0][0].gaussian_dim, sets[0][0].force_sh_3d, analytic_sh_gradients())
+        torch.cuda.synchronize()
+        return stage, sink, per_view, dsh
+
+    st_a, sink_a, pv_a, dsh_a = run(False)
+    st_b, sink_b, pv_b, dsh_b = run(True)
+    live_a, live_b = (st_a[:, :, :3] != 0).any(2), (st_b[:, :, :3] != 0).any(2)
+    assert torch.equal(live_a, live_b) and live_a.any() and not live_a.all()
+    # a live record: 8 numbers; a dead one: only its first four are written (zeros) -- compare what is defined
+    a = torch.where(live_a[..., None], st_a, torch.zeros_like(st_a))
+    b = torch.where(live_b[..., None], st_b, torch.zeros_like(st_b))
+    sc = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 1e-5 * sc, ((a - b).abs().max().item(), sc)
+    assert float(st_a[:, :, :4][~live_a].abs().max()) == 0.0 and float(st_b[:, :, :4][~live_b].abs().max()) == 0.0
+    for k in sink_a:
+        if k == "dL_dsh":
+            continue   # deferred: built by the flush below
+        # the two runs sum the blend backward's float atomics in different orders; the covariance-chain gradients amplify that
+        # rounding noise (cancelling sums, see test_gpu_parity._timed_path_vs_oracle): 3e-4 of the tensor scale
+        sc = max(1e-6, sink_a[k].abs().max().item())
+        err = (sink_a[k] - sink_b[k]).abs().max().item()
+        assert err <= 3e-4 * sc, (k, err, sc)
+    sc = dsh_a.abs().max().item()
+    assert (dsh_a - dsh_b).abs().max().item() <= 1e-5 * sc
+    for va, vb in zip(pv_a, pv_b):   # per-view outputs: viewspace gradient, colour gradient, covariance gradient
+        for i in (0, 1, 4):
+            sc = max(1e-6, va[i].abs().max().item())
+            assert (va[i] - vb[i]).abs().max().item() <= 1e-4 * sc, i
