@@ -157,7 +157,7 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
           opacity_reset_interval: int = 3000, densify_grad_threshold: float = 2e-4, densify_grad_t_threshold: float = 2e-4 / 40,
           thresh_opa_prune: float = 0.005, percent_dense: float = 0.01, cameras_extent: Optional[float] = None,
           densify_until_num_points: int = -1, on_densify: Optional[Callable] = None, log_every: int = 0,
-          log: Callable[[str], None] = print) -> Dict[str, List[float]]:
+          log: Callable[[str], None] = print, spatial_order: bool = True) -> Dict[str, List[float]]:
     """The reference's training loop (train.py:82-254) over ``cameras`` / ``gts`` (all views, identical on every rank;
     each rank renders its FrameShard slice).  Returns the logged history {"iteration", "loss", "psnr"}.
     Densification (train.py:229-244) runs when ``cameras_extent`` is given: every rank takes the same decisions from the
@@ -167,7 +167,20 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
     raises the spatial degree until it reaches the model's maximum, then the time degree.  ``sh_degree_start`` = (0, 0) is
     the reference's training from scratch (GaussianModel starts at degree 0 / 0); None keeps the model's current active
     degrees (resuming / fine-tuning a model whose coefficients are already populated).  ``white_background`` adds the
-    reference's extra opacity reset at ``densify_from_iter`` (train.py:243)."""
+    reference's extra opacity reset at ``densify_from_iter`` (train.py:243).
+    ``spatial_order``: the model is kept in Morton order of the Gaussians' positions (train_host.spatial_sort: at the start and
+    after every densification, when the statistics have just been reset) -- a memory-layout choice with no effect on the
+    arithmetic; every rank derives the same permutation from its (identical) parameters."""
+    from .train_host import spatial_sort
+
+    def resort(stats=None):
+        perm = spatial_sort(model, optimizer)
+        if stats is not None:   # everything else that is indexed by Gaussian follows the model
+            stats.xyz_gradient_accum, stats.t_gradient_accum = stats.xyz_gradient_accum[perm], stats.t_gradient_accum[perm]
+            stats.denom, stats.max_radii2D = stats.denom[perm], stats.max_radii2D[perm]
+
+    if spatial_order:
+        resort()
     shard = iter(FrameShard(len(cameras), batch_size, world_size, rank, seed))
     steppipe = StepPipeline(model, optimizer, world_size=world_size, lambda_dssim=lambda_dssim)
     stats = DensificationStats(model.P, model.flat.device, world_size)
@@ -196,6 +209,8 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
                         size_threshold = 20 if iteration > opacity_reset_interval else None
                         rep = densify_and_prune(model, optimizer, stats, densify_grad_threshold, thresh_opa_prune, cameras_extent,
                                                 size_threshold, densify_grad_t_threshold, percent_dense=percent_dense, generator=gen)
+                        if spatial_order:
+                            resort(stats)
                         steppipe.sink = model.grad_sink()
                         if rank == 0 and log_every:
                             log("[it %5d] densify: %d -> %d Gaussians (%d cloned, %d split)" % (iteration, rep["P_old"], rep["P_new"],

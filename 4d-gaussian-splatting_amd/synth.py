@@ -148,3 +148,28 @@ def make_upstream_grads(W: int, H: int, seed: int = 1, scale: float = 1.0) -> Di
         "grad_color": randn(3, H, W), "grad_depth": randn(1, H, W),
         "grad_alpha": randn(1, H, W), "grad_flow": randn(2, H, W),
     }
+
+
+PER_GAUSSIAN_KEYS = ("means3D", "ts", "scales", "scales_t", "rotations", "rotations_r", "opacities", "shs", "flow_2d")
+
+
+def morton_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation that sorts points by the Morton (Z-order) code of their position quantised to ``bits`` bits per axis."""
+    p = xyz.detach().cpu().double()
+    lo, hi = p.min(0).values, p.max(0).values
+    q = ((p - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
+    code = torch.zeros(p.shape[0], dtype=torch.long)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code, stable=True)
+
+
+def permute_scene(scene: Dict[str, object], perm: torch.Tensor) -> Dict[str, object]:
+    """The same scene with its Gaussians stored in another order (every per-Gaussian tensor permuted alike): renders the same
+    images; only the memory order -- hence the coherence of everything the kernels do per consecutive Gaussians -- changes."""
+    out = dict(scene)
+    for k in PER_GAUSSIAN_KEYS:
+        if isinstance(out.get(k), torch.Tensor):
+            out[k] = out[k][perm].contiguous()
+    return out

@@ -297,6 +297,43 @@ def make_optimizer(model: GaussianParams) -> FlatAdam:
     return FlatAdam(model)
 
 
+def morton_permutation(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation (on xyz's device) that puts points into Morton (Z-order) order of their positions quantised to ``bits`` bits
+    per axis; ties keep their order (stable), so the result is a pure function of the positions."""
+    p = xyz.detach().double()
+    lo, hi = p.min(0).values, p.max(0).values
+    q = ((p - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
+    code = torch.zeros(p.shape[0], dtype=torch.long, device=p.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code, stable=True)
+
+
+@torch.no_grad()
+def reorder_gaussians(model: GaussianParams, optimizer: "FlatAdam", perm: torch.Tensor) -> None:
+    """Stores the model's Gaussians in the order ``perm`` (row j of every parameter tensor and of both Adam moments becomes the old
+    row perm[j]).  Renders the same images and takes the same optimizer steps: only the memory order changes."""
+    bufs = [model.flat] + ([optimizer.exp_avg, optimizer.exp_avg_sq] if optimizer is not None else [])
+    for name, rf in zip(model.NAMES, model.row_floats()):
+        b, e = model.offsets[name]
+        for buf in bufs:
+            seg = buf[b:e].view(model.P, rf)
+            seg.copy_(seg[perm])
+
+
+def spatial_sort(model: GaussianParams, optimizer: "FlatAdam" = None) -> torch.Tensor:
+    """Keeps the model in Morton order of the Gaussians' positions (call it when the set of Gaussians changes: after loading,
+    after every densification; harness.train does).  Consecutive Gaussians then project to neighbouring pixels from any
+    camera, so a workgroup of the tile-binning passes touches a few dozen tile lists instead of all of them: its scattered
+    8-byte stores land in runs, its counter flushes in a few cache lines (measured at C3: scatter 53 -> 34 us, count 14 -> 10 us,
+    forward 0.281 -> 0.264 ms, step +2 %; DESIGN.md).  The reference appends new Gaussians at the end (gaussian_model.py:441-470);
+    the order of the model is not part of its semantics.  Returns the permutation applied."""
+    perm = morton_permutation(model.params["_xyz"].data)
+    reorder_gaussians(model, optimizer, perm)
+    return perm
+
+
 def allreduce_gradients(model: GaussianParams, world_size: int, average: bool = True) -> None:
     """One collective over the flat gradient bucket; grads become the mean over ranks (loss / batch_size).
     ``average=False``: plain SUM, for callers that already scaled their loss by 1 / world_size (saves one pass

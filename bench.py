@@ -82,6 +82,10 @@ def parse_args():
                     help="N = 1 only: steps of the DROP-IN leg -- a reference-style model (separate parameters, torch.cat features, "
                          "PyTorch activations, torch.optim.Adam over 9 groups) through this package's render() + autograd + the "
                          "reference's PyTorch loss: what a user of the reference gets by swapping one import (0 = skip)")
+    ap.add_argument("--spatial-order-steps", type=int, default=10,
+                    help="steps of the extra leg that re-times the step with the model stored in Morton order of the Gaussians' "
+                         "positions (train_host.spatial_sort -- what fdgs.harness.train keeps after every densification) instead of the "
+                         "generator's random order: spatial_order_images_s / spatial_order_forward_ms (0 = skip)")
     ap.add_argument("--no-loss", action="store_true", help="debug: sum() loss instead of L1 + SSIM")
     ap.add_argument("--reference-host", action="store_true",
                     help="host side exactly as the reference: render() on PyTorch activations, autograd gradient accumulation")
@@ -413,6 +417,18 @@ def main():
     R_timed = sum(_R_LOG) / max(len(_R_LOG), 1)
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]  # noqa: E731
 
+    # digest of the parameters after all steps (tests compare N ranks x B views with one rank x N B views: the same update)
+    param_digest = [float(model.flat.double().sum()), float(model.flat.double().abs().sum())]
+    # frame-parallel replicas must hold bit-identical parameters after the timed steps (every rank applied the same update)
+    replicas_identical = None
+    if world > 1:
+        import torch.distributed as dist
+        digest = torch.stack([model.flat.double().sum(), model.flat.double().abs().sum()])
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+
     # forward-only rate (the metric's second half), outside the train-step timing
     n_fwd = args.steps * B
 
@@ -464,6 +480,34 @@ def main():
                   "what": "rasterizer forward + backward only (all four upstream gradients given), one stream, %d views: pairs with cpu_baseline" % n_fwd}
         del gacc, up4
 
+    # the same step with the model stored in Morton order (a memory-layout choice of the trainer, no effect on the arithmetic)
+    spatial = None
+    if use_pipeline and args.spatial_order_steps > 0:
+        train_host.spatial_sort(model, opt)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        barrier(world)
+        ts0 = time.perf_counter()
+        for _ in range(args.spatial_order_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        barrier(world)
+        dts = max_over_ranks(time.perf_counter() - ts0, world, dev)
+        with torch.no_grad():
+            for _ in range(10):
+                forward_only(cam)
+            torch.cuda.synchronize(dev)
+            tf0 = time.perf_counter()
+            for i in range(n_fwd):
+                forward_only(cams[i % B])
+            torch.cuda.synchronize(dev)
+            dtf = max_over_ranks(time.perf_counter() - tf0, world, dev)
+        spatial = {"images_s": round(world * B * args.spatial_order_steps / dts, 2), "ms_per_step": round(dts / args.spatial_order_steps * 1e3, 4),
+                   "forward_ms": round(dtf / n_fwd * 1e3, 4), "steps": args.spatial_order_steps,
+                   "what": "the same step and forward with the Gaussians stored in Morton order of their positions (train_host.spatial_sort; "
+                           "fdgs.harness.train keeps the model that way): `value` is measured on the generator's random order"}
+
     # host cost per view: the same step on a scene so small that the GPU work is negligible (wall time ~ host time)
     host_ms_per_view = None
     if use_pipeline and rank == 0 and args.host_cost_steps > 0:
@@ -486,18 +530,6 @@ def main():
     dropin = None
     if world == 1 and rank == 0 and args.dropin_steps > 0:
         dropin = dropin_leg(args, scene, cams, gts, pipe, bg, dev, B)
-
-    # digest of the parameters after all steps (tests compare N ranks x B views with one rank x N B views: the same update)
-    param_digest = [float(model.flat.double().sum()), float(model.flat.double().abs().sum())]
-    # frame-parallel replicas must hold bit-identical parameters after the timed steps (every rank applied the same update)
-    replicas_identical = None
-    if world > 1:
-        import torch.distributed as dist
-        digest = torch.stack([model.flat.double().sum(), model.flat.double().abs().sum()])
-        lo, hi = digest.clone(), digest.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        replicas_identical = bool(torch.equal(lo, hi))
 
     if rank != 0:
         return
@@ -576,6 +608,9 @@ def main():
     }
     out["rccl_ranks"] = world
     out["backend"] = backend if backend else "none (single process)"
+    if spatial:
+        out["spatial_order_images_s"] = spatial["images_s"]
+        out["spatial_order"] = spatial
     if raster:
         out["raster_images_s"] = raster["images_s"]
         out["raster"] = raster

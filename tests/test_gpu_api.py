@@ -502,3 +502,36 @@ def test_sh_backward_batch_matches_per_view(cfg, gpu_device):
         for i in (0, 1, 4):
             sc = max(1e-6, va[i].abs().max().item())
             assert (va[i] - vb[i]).abs().max().item() <= 1e-4 * sc, i
+
+
+def test_spatial_sort_renders_the_same_images(gpu_device):
+    """The order in which the model stores its Gaussians is not part of its semantics: after train_host.spatial_sort the forward
+    gives the same image (contributions are blended in depth order; only exact depth ties could change their order), the per-Gaussian
+    outputs are the permuted ones, and one optimizer step moves every Gaussian as before."""
+    from fdgs import train_host
+    from fdgs.fused import raw_forward, raw_settings
+    from fdgs.pipeline import StepPipeline
+    scene = synth.make_scene(synth.SceneConfig("so", 20000, 320, 240, 3, 2, 0.03, 10.0, True, 4, False), seed=8)
+    pipe = train_host.PipelineFlags()
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / 2 * scene["time_duration"]) for b in range(2)]
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(gpu_device) for _ in range(2)]
+    ma, mb = train_host.GaussianParams(scene, gpu_device), train_host.GaussianParams(scene, gpu_device)
+    oa, ob = train_host.make_optimizer(ma), train_host.make_optimizer(mb)
+    perm = train_host.spatial_sort(mb, ob)
+    outs = []
+    for m in (ma, mb):
+        rs, tens = raw_settings(cams[0], m, pipe, bg)
+        outs.append(raw_forward(rs, *tens))
+    (Ra, ca, fa, da, Ta, ra, *_), (Rb, cb, fb, db, Tb, rb, *_) = outs
+    assert Ra == Rb and torch.equal(rb, ra[perm])
+    assert (ca - cb).abs().max().item() <= 1e-6 and (Ta - Tb).abs().max().item() <= 1e-6 and (da - db).abs().max().item() <= 1e-5
+    for m, o in ((ma, oa), (mb, ob)):
+        StepPipeline(m, o, world_size=1, lambda_dssim=0.2).step(cams, gts, pipe, bg)
+    torch.cuda.synchronize()
+    for n in ma.NAMES:
+        a, b = ma.params[n].detach()[perm], mb.params[n].detach()
+        # Adam's first step moves a parameter by ~lr whatever the gradient's size: where a gradient is float-atomics noise around
+        # zero its sign may differ between two runs (2 lr)
+        assert ((a - b).abs() > 2e-3).float().mean().item() <= 2e-3, n

@@ -72,7 +72,7 @@ def test_bench_refuses_more_ranks_than_gpus(gpu_device):
 def _run_bench(nproc, views, extra=()):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--workload", "C2",
-              "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0", "--dropin-steps", "0"] + list(extra)
+              "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0", "--dropin-steps", "0", "--spatial-order-steps", "0"] + list(extra)
     if nproc == 1:
         cmd = [sys.executable] + common
     else:

@@ -92,3 +92,29 @@ def test_sh_schedule_follows_oneupSHdegree():
     import pytest
     with pytest.raises(ValueError, match="multiple of 4"):
         opt.step_range(2, 10)
+
+
+def test_spatial_sort_permutes_parameters_and_moments_alike():
+    """train_host.spatial_sort: rows of every parameter tensor and of both Adam moments move together; the Morton permutation is a
+    stable, deterministic function of the positions; neighbours in the new order are neighbours in space."""
+    from fdgs import synth, train_host
+    scene = synth.make_scene(synth.SceneConfig("h", 3000, 64, 48, 1, 0, 0.03, 1.0, True, 4, True), seed=2)
+    m = train_host.GaussianParams(scene, torch.device("cpu"))
+    o = train_host.make_optimizer(m)
+    o.exp_avg.copy_(torch.arange(m.flat.numel(), dtype=torch.float32))
+    o.exp_avg_sq.copy_(torch.arange(m.flat.numel(), dtype=torch.float32) * 2)
+    before = {n: m.params[n].detach().clone() for n in m.NAMES}
+    ea = {n: o.exp_avg[m.offsets[n][0]:m.offsets[n][1]].clone().view(m.P, -1) for n in m.NAMES}
+    perm = train_host.spatial_sort(m, o)
+    assert torch.equal(perm, train_host.morton_permutation(before["_xyz"])) and torch.equal(torch.sort(perm).values, torch.arange(m.P))
+    for n in m.NAMES:
+        assert torch.equal(m.params[n].detach(), before[n][perm]), n
+        b, e = m.offsets[n]
+        assert torch.equal(o.exp_avg[b:e].view(m.P, -1), ea[n][perm]), n
+        assert torch.equal(o.exp_avg_sq[b:e].view(m.P, -1), 2 * ea[n][perm]), n
+    # already sorted: the permutation is the identity (stable sort)
+    assert torch.equal(train_host.morton_permutation(m.params["_xyz"].detach()), torch.arange(m.P))
+    xyz = m.params["_xyz"].detach()
+    step_sorted = (xyz[1:] - xyz[:-1]).norm(dim=1).mean().item()
+    step_random = (before["_xyz"][1:] - before["_xyz"][:-1]).norm(dim=1).mean().item()
+    assert step_sorted < 0.25 * step_random
