@@ -26,7 +26,8 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_sh_stages
 
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
-                 fuse_sh_adam: bool = True, gather_max_views: int = 16, split_colour: bool = False, batch_views: bool = False):
+                 fuse_sh_adam: bool = True, gather_max_views: int = 16, split_colour: bool = False, batch_views: bool = False,
+                 sh_group: int = 1):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -46,6 +47,12 @@ class StepPipeline:
         # streams it is a wash (3.04 -> 3.04-3.10 ms): the batched head and tail of the step have nothing to overlap with.  Off by
         # default.
         self.batch_views = bool(batch_views)
+        # SH backward of ``sh_group`` consecutive views in one pass over the coefficients (fdgs_sh_backward_batch) on stream B, with
+        # the forwards left per view: the batch kernel takes two views in 66 us against 2 x 50 us for the per-view kernel (its lanes
+        # pair up on a Gaussian, one view each), four in 120-135 us.  1 (default): the per-view SH backward inside
+        # fdgs_rasterize_backward -- in the two-stream step the grouping is a loss (pairs: 1330 -> 1308 images/s at C3, all four: 1278),
+        # because a group's SH + geometry backward waits for the group's last blend backward.
+        self.sh_group = int(sh_group)
         self._gacc_b = None   # [B, P, 16] persistent always-zero accumulators, one per view (the batched SH backward reads all of them)
         dev = model.flat.device
         self.dev = dev
@@ -91,7 +98,7 @@ class StepPipeline:
         sh_handle = []
         sh_gather = []     # gather: (work, stages of all ranks)
         sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
-        if self.batch_views and B > 1 and defer_sh:
+        if (self.batch_views or self.sh_group > 1) and B > 1 and defer_sh:
             return self._step_batched(cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped)
         for b in range(B):
             with torch.cuda.stream(self.sF):
@@ -199,23 +206,29 @@ class StepPipeline:
                 sh_handle.append(allreduce_sh_begin(m, self.world))
 
     def _step_batched(self, cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped):
-        """step() with the views' SH work batched (see __init__): stream F: geometry of every view, ONE colour pass, then per view
-        binning + blend; stream B: per view loss + blend backward, then ONE SH backward pass, the views' geometry backward, the
-        optimizer.  Same arithmetic per view as the unbatched step (forward bit-identical; tests/test_gpu_api.py)."""
+        """step() with SH work of several views done in one pass over the coefficients (see __init__).
+        ``batch_views``: stream F starts with the geometry of every view and ONE colour pass, then per view binning + blend.
+        SH backward: stream B runs loss + blend backward per view and, after every ``sh_group`` views (all of them with
+        ``batch_views``), ONE SH backward pass for the group followed by the group's geometry backward.  Same arithmetic per view as
+        the unbatched step (forward bit-identical; tests/test_gpu_api.py)."""
         B, m = len(cams), self.model
+        G = B if self.batch_views else max(1, min(self.sh_group, B))
         if self._gacc_b is None or self._gacc_b.shape[0] != B or self._gacc_b.shape[1] != m.P:
             with torch.cuda.stream(self.sB):
                 self._gacc_b = torch.zeros((B, m.P, 16), dtype=torch.float32, device=self.dev)
-        results, losses, keep, pend, loss_handles = [], [], [], [], []
+        results, losses, keep, pend, grads_of = [], [], [], [], {}
         with torch.cuda.stream(self.sF):
             sets = [raw_settings(c, m, pipe, bg, scaling_modifier) for c in cams]
             (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = sets[0][1]
-            handles = raw_preprocess_batch([s[0] for s in sets], xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var)
+            handles = [None] * B
+            if self.batch_views:
+                handles = raw_preprocess_batch([s[0] for s in sets], xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var)
         for b in range(B):
             rs = sets[b][0]
             with torch.cuda.stream(self.sF):
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
-                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b])
+                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
+                    split_colour=self.split_colour and handles[b] is None)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
@@ -224,16 +237,20 @@ class StepPipeline:
                 pend.append(raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r,
                                          prefilter_var, geom, R, binb, img, g_color, None, None, None, self.sink, b > 0,
                                          grad_accum=self._gacc_b[b], sh_stage=self._sh_stage[b], begin_only=True))
-            loss_handles.append(loss_handle)
+                losses.append(l1_ssim_loss(loss_handle))
+                if (b + 1) % G == 0 or b == B - 1:
+                    first = b - (b % G)
+                    _dgr._C.sh_backward_batch(pend[first:b + 1])
+                    if b == B - 1:   # the stages of the step are complete
+                        self._after_sh(rs, fuse, gather, True, sh_handle, sh_gather, sh_stepped)
+                    for v in range(first, b + 1):
+                        results_v = _dgr._C.backward_finish(pend[v])
+                        keep.append(results_v)
+                        grads_of[v] = results_v[0]
             keep.append((geom, binb, img, out_means3D, g_color, T))
             results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow, "num_rendered": R})
-        with torch.cuda.stream(self.sB):
-            _dgr._C.sh_backward_batch(pend)
-            self._after_sh(rs, fuse, gather, True, sh_handle, sh_gather, sh_stepped)
-            for b in range(B):
-                grads = _dgr._C.backward_finish(pend[b])
-                results[b]["viewspace_grad"] = grads[0]
-                losses.append(l1_ssim_loss(loss_handles[b]))
+        for v in range(B):
+            results[v]["viewspace_grad"] = grads_of[v]
         self._optimizer_tail(rs, fuse, gather, sh_handle, sh_gather, sh_stepped)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)

@@ -94,6 +94,8 @@ def parse_args():
                     help="fused kernels driven through autograd (render_raw + fused_l1_ssim + backward()) on one stream, "
                          "instead of the explicit two-stream step pipeline (fdgs/pipeline.py)")
     ap.add_argument("--no-overlap", action="store_true", help="step pipeline on a single stream (A/B for the overlap)")
+    ap.add_argument("--sh-group", type=int, default=1,
+                    help="SH backward of this many consecutive views in one pass over the coefficients (fdgs_sh_backward_batch); 1: per view")
     ap.add_argument("--batch-views", action="store_true",
                     help="A/B: SH colours and SH backward of the step's views in one pass over the coefficients each "
                          "(fdgs_preprocess_batch / fdgs_sh_backward_batch): fewer bytes, but a serial head and tail of the step")
@@ -326,7 +328,7 @@ def main():
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
                                 gather_max_views=0 if args.dense_sh_exchange else 16, split_colour=args.split_colour == "all",
-                                batch_views=args.batch_views)
+                                batch_views=args.batch_views, sh_group=args.sh_group)
 
     def step():
         if use_pipeline:
@@ -358,7 +360,7 @@ def main():
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.
     if use_pipeline:
         stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
-                                  gather_max_views=0 if args.dense_sh_exchange else 16, batch_views=args.batch_views)
+                                  gather_max_views=0 if args.dense_sh_exchange else 16, batch_views=args.batch_views, sh_group=args.sh_group)
         stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)  # noqa: E731
     else:
         stage_step = step

@@ -345,8 +345,8 @@ def test_sh_adam_fused_is_flush_plus_adam(gpu_device, D, D_t, M, sh3d, analytic)
 
 
 @pytest.mark.parametrize("overlap,fuse,B", [(True, True, 3), (False, True, 3), (True, False, 3), (True, True, 1), (True, False, 1)])
-@pytest.mark.parametrize("batch", [True, False], ids=["batched-sh", "per-view-sh"])
-def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B, batch):
+@pytest.mark.parametrize("batch,group", [(True, 1), (False, 2), (False, 1)], ids=["batched-views", "sh-pairs", "per-view-sh"])
+def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B, batch, group):
     """fdgs.pipeline.StepPipeline (explicit forward / fused loss / backward on two HIP streams, no autograd) performs
     the same optimizer step as render_raw + fused_l1_ssim + backward() + Adam on one stream."""
     from fdgs import train_host
@@ -373,7 +373,7 @@ def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B, batch
         oa.step()
 
     mp = train_host.GaussianParams(scene, gpu_device)
-    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap, fuse_sh_adam=fuse, batch_views=batch)
+    sp = StepPipeline(mp, train_host.make_optimizer(mp), world_size=1, lambda_dssim=0.2, overlap=overlap, fuse_sh_adam=fuse, batch_views=batch, sh_group=group)
     got_losses = []
     for _ in range(2):
         results, losses = sp.step(cams, gts, pipe, bg)
