@@ -40,9 +40,9 @@ class StepPipeline:
         self.gather_max_views = int(gather_max_views)
         self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
         # View batching (opt-in, B > 1): the SH coefficients -- 12 M bytes per Gaussian, most of what preprocess and SH backward
-        # read -- are the same for every view of the step.  The views' geometry still runs per view, but their SH colours come
-        # from ONE pass over the coefficients before the first view's binning (fdgs_preprocess_batch), and their SH backward from
-        # ONE pass after the last view's blend backward (fdgs_sh_backward_batch); the views' geometry backward follows it.
+        # read -- are the same for every view of the step.  ``batch_views``: the views' geometry still runs per view, but their SH
+        # colours come from ONE pass over the coefficients before the first view's binning (fdgs_preprocess_batch).  ``sh_group``
+        # (below): the SH backward of groups of views from ONE pass (fdgs_sh_backward_batch).
         # Measured at C3, 4 views per step: 120 us less kernel time per step, 3.66 -> 3.56 ms on one stream; with the two
         # streams it is a wash (3.04 -> 3.04-3.10 ms): the batched head and tail of the step have nothing to overlap with.  Off by
         # default.
@@ -98,14 +98,21 @@ class StepPipeline:
         sh_handle = []
         sh_gather = []     # gather: (work, stages of all ranks)
         sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
-        if (self.batch_views or self.sh_group > 1) and B > 1 and defer_sh:
+        if self.sh_group > 1 and B > 1 and defer_sh:
             return self._step_batched(cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped)
+        handles = [None] * B
+        if self.batch_views and B > 1:
+            # the SH colours of all views in one pass over the coefficients, ahead of the first view's binning
+            with torch.cuda.stream(self.sF):
+                sets = [raw_settings(c, m, pipe, bg, scaling_modifier) for c in cams]
+                handles = raw_preprocess_batch([s_[0] for s_ in sets], *sets[0][1])
         for b in range(B):
             with torch.cuda.stream(self.sF):
                 rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
                     cams[b], m, pipe, bg, scaling_modifier)
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
-                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, split_colour=self.split_colour)
+                    rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
+                    split_colour=self.split_colour and handles[b] is None)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
@@ -151,7 +158,7 @@ class StepPipeline:
         # The returned tensors live in the F / B streams' allocator pools.  `main` has waited for both streams, and the
         # next step() makes both streams wait for `main` first, so they are safe to read on `main` until then
         # (no record_stream: it would defer every free by an event query and grow the pools).
-        del keep
+        del keep, handles
         return results, losses
 
     def _optimizer_tail(self, rs, fuse, gather, sh_handle, sh_gather, sh_stepped):
@@ -206,13 +213,13 @@ class StepPipeline:
                 sh_handle.append(allreduce_sh_begin(m, self.world))
 
     def _step_batched(self, cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped):
-        """step() with SH work of several views done in one pass over the coefficients (see __init__).
-        ``batch_views``: stream F starts with the geometry of every view and ONE colour pass, then per view binning + blend.
-        SH backward: stream B runs loss + blend backward per view and, after every ``sh_group`` views (all of them with
-        ``batch_views``), ONE SH backward pass for the group followed by the group's geometry backward.  Same arithmetic per view as
+        """step() with the SH backward of ``sh_group`` consecutive views done in one pass over the coefficients (see __init__):
+        stream B runs loss + blend backward per view and, after every ``sh_group`` views, ONE SH backward pass for the group
+        followed by the group's geometry backward.  (``batch_views``: stream F starts with the geometry of every view and ONE
+        colour pass, then per view binning + blend.)  Same arithmetic per view as
         the unbatched step (forward bit-identical; tests/test_gpu_api.py)."""
         B, m = len(cams), self.model
-        G = B if self.batch_views else max(1, min(self.sh_group, B))
+        G = max(1, min(self.sh_group, B))
         if self._gacc_b is None or self._gacc_b.shape[0] != B or self._gacc_b.shape[1] != m.P:
             with torch.cuda.stream(self.sB):
                 self._gacc_b = torch.zeros((B, m.P, 16), dtype=torch.float32, device=self.dev)

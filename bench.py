@@ -82,6 +82,8 @@ def parse_args():
                     help="N = 1 only: steps of the DROP-IN leg -- a reference-style model (separate parameters, torch.cat features, "
                          "PyTorch activations, torch.optim.Adam over 9 groups) through this package's render() + autograd + the "
                          "reference's PyTorch loss: what a user of the reference gets by swapping one import (0 = skip)")
+    ap.add_argument("--spatial-order", action="store_true",
+                    help="analysis: the whole run on the Morton-ordered model (train_host.spatial_sort before the warm-up); noted in config.workload")
     ap.add_argument("--spatial-order-steps", type=int, default=10,
                     help="steps of the extra leg that re-times the step with the model stored in Morton order of the Gaussians' "
                          "positions (train_host.spatial_sort -- what fdgs.harness.train keeps after every densification) instead of the "
@@ -312,6 +314,8 @@ def main():
     scene = synth.make_scene(cfg, seed=0)
     model = train_host.GaussianParams(scene, dev)
     opt = train_host.make_optimizer(model)
+    if args.spatial_order:
+        train_host.spatial_sort(model, opt)
     pipe = train_host.PipelineFlags()
     B = max(1, args.views_per_step)
     # frame-parallel: the N*B views of one optimizer step are N*B different timestamps; rank r takes views r*B .. r*B+B-1
@@ -591,7 +595,7 @@ def main():
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
+        "config": {"workload": ("[model stored in Morton order] " if args.spatial_order else "") + "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
                                                                         M, cfg.rot_4d, B, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else (", fused activations, explicit fwd/loss/bwd on %s" % ("one stream" if args.no_overlap else "two HIP streams") if use_pipeline else ", fused activations, autograd")),
                    "num_rendered": int(round(R_timed)), "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,

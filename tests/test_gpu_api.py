@@ -345,7 +345,7 @@ def test_sh_adam_fused_is_flush_plus_adam(gpu_device, D, D_t, M, sh3d, analytic)
 
 
 @pytest.mark.parametrize("overlap,fuse,B", [(True, True, 3), (False, True, 3), (True, False, 3), (True, True, 1), (True, False, 1)])
-@pytest.mark.parametrize("batch,group", [(True, 1), (False, 2), (False, 1)], ids=["batched-views", "sh-pairs", "per-view-sh"])
+@pytest.mark.parametrize("batch,group", [(True, 1), (True, 4), (False, 2), (False, 1)], ids=["batched-colours", "all-batched", "sh-pairs", "per-view"])
 def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B, batch, group):
     """fdgs.pipeline.StepPipeline (explicit forward / fused loss / backward on two HIP streams, no autograd) performs
     the same optimizer step as render_raw + fused_l1_ssim + backward() + Adam on one stream."""
