@@ -249,7 +249,7 @@ namespace fdgs
 	// Position of gradient slot s of an entry: AUX (s = record word 0..11): (s / 3) * 4 + s % 3; colour-only (slots = words
 	// 0,1,2,6..11): 0,1,2,4,5,8,9,10,12 -- where the joint reduction above leaves them (lane h of a half-row: positions 2 h and
 	// 2 h + 1); the other positions hold duplicates nobody reads.
-	constexpr int ACC_GROUP = 8;
+	constexpr int ACC_GROUP = 4;
 
 	// AUX = false: only the colour image carries an upstream gradient (dL_dout_depth / _alpha / _flow are NULL = zero),
 	// the usual case in training (photometric loss on the render only): the depth / flow / mask terms drop out.
