@@ -5,10 +5,10 @@
 // 12*M bytes of dL_dsh with a 12*M-byte stride between threads.  At M = 48 that is 576 B in and 576 B out per
 // Gaussian -- 80 % of all bytes the whole per-Gaussian backward moves -- so it gets its own kernel here:
 //   * every output of the kernel is linear in the Gaussian's dL_dRGB, and a Gaussian that is visible but contributed to no
-//     pixel (occluded, or too faint everywhere: 58 % of the visible ones on C3) has dL_dRGB == 0 exactly.  A wave first
-//     scans a span of 128 consecutive Gaussians and ballot-compacts the LIVE ones (those with a colour gradient) into a list;
+//     pixel (occluded, or too faint everywhere: 58 % of the visible ones on C3) has dL_dRGB == 0 exactly.  A wave walks
+//     its range of consecutive Gaussians 64 at a time and ballot-compacts the LIVE ones (those with a colour gradient) into a list;
 //     the others only get their zeros (the stage record / the dL_dsh row; their accumulator words 12..15 are zero already);
-//   * the live Gaussians are then taken 64 at a time, one per lane: their rows are staged block by block (16 coefficients
+//   * whenever 64 live Gaussians are waiting (and at the end of the range) they are evaluated, one per lane: their rows are staged block by block (16 coefficients
 //     = 192 B per Gaussian) through a wave-private LDS tile with coalesced dwordx4 loads (gathered rows, contiguous runs);
 //   * each lane walks ITS Gaussian's row in LDS (row stride 49 floats: conflict free), accumulates the
 //     direction / time dot products in registers and overwrites the row with dL_dsh;
@@ -30,7 +30,6 @@ namespace fdgs
 {
 	constexpr int SHB_STRIDE = 49;   // LDS row stride in floats (odd: lane-per-row access is conflict free)
 	constexpr int SHB_CH = 12;       // float4 chunks per Gaussian and block (16 coefficients x 3 / 4)
-	constexpr int SHB_SPAN = 128;    // consecutive Gaussians a wave scans for live ones
 	constexpr int SHB_ROWS = WAVE;   // live Gaussians evaluated per round, one per lane (tile: 12.5 KB)
 
 	struct ShBwdArgs
@@ -179,83 +178,100 @@ namespace fdgs
 
 	// One wave per workgroup: the tile is wave-private, so no workgroup barrier is needed anywhere (LDS
 	// operations of one wave execute in order) and waves of different phases (load / compute / store) overlap freely.
+	// The launch is 1.5 waves per wave slot the device has for this kernel (launcher), wave w takes the CHUNKS of 64 Gaussians
+	// w, w + G, w + 2 G, ... (G = waves of the launch): chunks that far apart have nothing to do with each other even when
+	// the model is stored in spatial order (where whole neighbourhoods are live or dead), so every wave gets about the same
+	// number of live Gaussians.  It collects them and evaluates whenever 64 are waiting (and what is left at the end): the
+	// evaluation's latency chain is paid per batch, and most waves need one.  (Fixed spans of 128 Gaussians per wave, the
+	// previous version, made 1.14 rounds of two batches each, 64 + 9 rows.)
+	// (A ticket counter handing out the chunks was built and measured at 0.19 ms: ~6700 returning atomics on one address.)
 	template <bool STAGE>
 	__global__ void __launch_bounds__(WAVE) sh_bwd_kernel(const ShBwdArgs a)
 	{
 		__shared__ float tile[SHB_ROWS * SHB_STRIDE];
-		__shared__ uint32_t s_list[SHB_SPAN];     // span-local indices of the live Gaussians, ascending
+		__shared__ uint32_t s_list[2 * WAVE];     // the live Gaussians waiting for evaluation
 		const int lane = threadIdx.x;
-		const int g0 = blockIdx.x * SHB_SPAN;
 		const size_t row_floats = (size_t)3 * a.M;
 		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
 		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
 		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
 		const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-		// ---- which Gaussians of the span carry a colour gradient (visible: backward.cu:873) ----
-		unsigned long long live_mask[SHB_SPAN / WAVE];
-		int n = 0;
-#pragma unroll
-		for (int h = 0; h < SHB_SPAN / WAVE; h++)
-		{
-			const int idx = g0 + h * WAVE + lane;
-			const bool valid = idx < a.P;
-			bool live = false;
-			if (valid && a.radii[idx] > 0)
-			{
-				const float3 dRGB = colour_gradient(a, idx);
-				live = dRGB.x != 0.f || dRGB.y != 0.f || dRGB.z != 0.f;
-			}
-			live_mask[h] = __ballot(live);
-			if (live) s_list[n + __popcll(live_mask[h] & lt_mask)] = (uint32_t)(h * WAVE + lane);
-			n += __popcll(live_mask[h]);
-			// a Gaussian without a colour gradient: all of its outputs are zero.  Record words 12..15 already are (the record is
-			// all zero when the blend backward starts and nobody else writes them); dL_dsh: below; the flush looks at dRGB only
-			if (STAGE && valid && !live) a.stage[2 * (size_t)idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-		}
-		__builtin_amdgcn_wave_barrier();
-
-		if (!STAGE && !a.accum)
-		{
-			// dL_dsh is fully written by this call: zero rows for the Gaussians without a colour gradient, zeros beyond the
-			// active degrees for the others (nothing to add when accumulating)
-			const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
-			const int span = min(SHB_SPAN, a.P - g0);
-			if (a.vec_ok && (written & 3) == 0)
-			{
-				const int RC = (int)row_floats / 4, total = span * RC;
-				const int dg = WAVE / RC, dq = WAVE - dg * RC;
-				int g = lane / RC, q = lane - g * RC;
-				for (int c = lane; c < total; c += WAVE)
-				{
-					const bool live = (live_mask[g >> 6] >> (g & 63)) & 1ull;
-					if (!live || 4 * q >= written)
-						*reinterpret_cast<float4*>(a.dL_dsh + (size_t)(g0 + g) * row_floats + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-					g += dg; q += dq;
-					if (q >= RC) { q -= RC; g++; }
-				}
-			}
-			else
-			{
-				const int rf = (int)row_floats, total = span * rf;
-				const int dg = WAVE / rf, dpos = WAVE - dg * rf;
-				int g = lane / rf, pos = lane - g * rf;
-				for (int e = lane; e < total; e += WAVE)
-				{
-					const bool live = (live_mask[g >> 6] >> (g & 63)) & 1ull;
-					if (!live || pos >= written) a.dL_dsh[(size_t)(g0 + g) * row_floats + pos] = 0.f;
-					g += dg; pos += dpos;
-					if (pos >= rf) { pos -= rf; g++; }
-				}
-			}
-		}
-
-		// ---- the live Gaussians, one per lane ----
 		const float3 campos = make_float3(a.campos[0], a.campos[1], a.campos[2]);
-		for (int r0 = 0; r0 < n; r0 += SHB_ROWS)
+		const int nchunks = (a.P + WAVE - 1) / WAVE;
+
+		int n = 0;      // live Gaussians waiting in s_list
+		int next = blockIdx.x;
+		bool more = true;
+		while (more || n > 0)
 		{
-			const int nrows = min(SHB_ROWS, n - r0);
-			const uint32_t* list = s_list + r0;
+			if (more)
+			{
+				const int base = next * WAVE;
+				if (next >= nchunks) { more = false; if (n == 0) break; }
+				else
+				{
+				next += gridDim.x;
+				const int g_end = a.P;
+				// ---- which of the next 64 Gaussians carry a colour gradient (visible: backward.cu:873) ----
+				const int idx = base + lane;
+				const bool valid = idx < g_end;
+				bool live = false;
+				if (valid && a.radii[idx] > 0)
+				{
+					const float3 dRGB = colour_gradient(a, idx);
+					live = dRGB.x != 0.f || dRGB.y != 0.f || dRGB.z != 0.f;
+				}
+				const unsigned long long live_mask = __ballot(live);
+				if (live) s_list[n + __popcll(live_mask & lt_mask)] = (uint32_t)idx;
+				n += __popcll(live_mask);
+				// a Gaussian without a colour gradient: all of its outputs are zero.  Record words 12..15 already are (the record is
+				// all zero when the blend backward starts and nobody else writes them); dL_dsh: below; the flush looks at dRGB only
+				if (STAGE && valid && !live) a.stage[2 * (size_t)idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+				__builtin_amdgcn_wave_barrier();
+
+				if (!STAGE && !a.accum)
+				{
+					// dL_dsh is fully written by this call: zero rows for the Gaussians without a colour gradient, zeros beyond the
+					// active degrees for the others (nothing to add when accumulating)
+					const int written = (nblocks - 1) * 48 + 3 * (nblocks > 1 ? 16 : ncoef0);
+					const int span = min(WAVE, g_end - base);
+					if (a.vec_ok && (written & 3) == 0)
+					{
+						const int RC = (int)row_floats / 4, total = span * RC;
+						const int dg = WAVE / RC, dq = WAVE - dg * RC;
+						int g = lane / RC, q = lane - g * RC;
+						for (int c = lane; c < total; c += WAVE)
+						{
+							const bool lv = (live_mask >> g) & 1ull;
+							if (!lv || 4 * q >= written)
+								*reinterpret_cast<float4*>(a.dL_dsh + (size_t)(base + g) * row_floats + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+							g += dg; q += dq;
+							if (q >= RC) { q -= RC; g++; }
+						}
+					}
+					else
+					{
+						const int rf = (int)row_floats, total = span * rf;
+						const int dg = WAVE / rf, dpos = WAVE - dg * rf;
+						int g = lane / rf, pos = lane - g * rf;
+						for (int e = lane; e < total; e += WAVE)
+						{
+							const bool lv = (live_mask >> g) & 1ull;
+							if (!lv || pos >= written) a.dL_dsh[(size_t)(base + g) * row_floats + pos] = 0.f;
+							g += dg; pos += dpos;
+							if (pos >= rf) { pos -= rf; g++; }
+						}
+					}
+				}
+				if (n < SHB_ROWS) continue;   // keep collecting
+				}
+			}
+
+			// ---- up to 64 waiting live Gaussians, one per lane ----
+			{
+			constexpr int g0 = 0;    // the list holds Gaussian indices
+			const int nrows = min(SHB_ROWS, n);
+			const uint32_t* list = s_list;
 			const bool live = lane < nrows;
 			const int idx = g0 + (int)list[live ? lane : 0];
 			float* row = tile + lane * SHB_STRIDE;
@@ -348,7 +364,34 @@ namespace fdgs
 				o.w = sh3d ? 0.f : s_dot(gt, dRGB);
 				reinterpret_cast<float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS)[3] = o;
 			}
+			// the Gaussians that did not fit into this batch move to the front of the list
+			const int left = n - nrows;
+			const uint32_t moved = lane < left ? s_list[nrows + lane] : 0u;
+			__builtin_amdgcn_wave_barrier();
+			if (lane < left) s_list[lane] = moved;
+			n = left;
+			__builtin_amdgcn_wave_barrier();
+			}
 		}
+	}
+
+	// wave slots of the device for a one-wave kernel (occupancy x CUs), per device
+	template <typename K>
+	static int resident_waves(K kernel)
+	{
+		int dev = 0, per_cu = 0, cus = 0;
+		if (hipGetDevice(&dev) != hipSuccess) return 2048;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+		return per_cu * cus;
+	}
+
+	// FDGS_SH_BWD_WAVES=n (probe switch): waves per launch instead of the device's slots
+	static int sh_bwd_waves_override()
+	{
+		static int v = -1;
+		if (v < 0) { const char* e = getenv("FDGS_SH_BWD_WAVES"); v = e ? max(0, atoi(e)) : 0; }
+		return v;
 	}
 
 	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out, const char* geom, hipStream_t stream)
@@ -365,8 +408,19 @@ namespace fdgs
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
 		a.stage = reinterpret_cast<float4*>(out.sh_stage);
-		if (out.sh_stage) hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(div_up(s.P, SHB_SPAN)), dim3(WAVE), 0, stream, a);
-		else hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(div_up(s.P, SHB_SPAN)), dim3(WAVE), 0, stream, a);
+		// one wave per wave slot the device has for this kernel (cached per device)
+		constexpr int MAXDEV = 64;
+		static int slots_of[2][MAXDEV] = {};   // same value whoever writes it first
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		const int k = out.sh_stage ? 1 : 0;
+		int& slots = slots_of[k][(unsigned)dev % MAXDEV];
+		if (slots == 0) slots = k ? resident_waves(sh_bwd_kernel<true>) : resident_waves(sh_bwd_kernel<false>);
+		// 1.5 waves per slot: ~1.5 chunks = ~55 live Gaussians per wave on C3, i.e. ONE evaluation batch for most waves and two
+		// rounds of them (C3, random / Morton order: 41 / 42 us; one wave per slot 43 / 50; spans of 128 as before 52 / 43)
+		const int grid = min(sh_bwd_waves_override() > 0 ? sh_bwd_waves_override() : slots + slots / 2, div_up(s.P, WAVE));
+		if (out.sh_stage) hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(grid), dim3(WAVE), 0, stream, a);
+		else hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(grid), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
 	}
 

@@ -52,17 +52,27 @@ namespace fdgs
 		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		// halo element i = tid, tid + 256, ...  ->  (row, column), carried along instead of divided out every trip
-		for (int i = tid, ly = tid / SW, lx = tid - (tid / SW) * SW; i < SHH * SW; i += STHREADS)
+		// halo element i = tid, tid + 256, ... -> (row, column).  All loads of the thread are issued before the first one is
+		// waited for (a rolled loop paid one global round trip per trip: 5 in a row)
 		{
-			const int gy = y0 + ly - SR, gx = x0 + lx - SR;
-			const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-			const size_t o = plane + (size_t)gy * W + gx;
-			v2f p = { 0.0f, 0.0f };                    // zero padding (F.conv2d padding = 5)
-			if (in) { p.x = img1[o]; p.y = img2[o]; }
-			s_in[ly][lx] = p;
-			ly += STHREADS / SW; lx += STHREADS % SW;
-			if (lx >= SW) { lx -= SW; ly++; }
+			constexpr int TRIPS = (SHH * SW + STHREADS - 1) / STHREADS;
+			v2f p[TRIPS];
+#pragma unroll
+			for (int t = 0; t < TRIPS; t++)
+			{
+				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
+				const int gy = y0 + ly - SR, gx = x0 + lx - SR;
+				const bool in = i < SHH * SW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+				const size_t o = in ? plane + (size_t)gy * W + gx : plane;   // branch-free: outside lanes read a valid address
+				const float vx = img1[o], vy = img2[o];
+				p[t] = in ? v2f{ vx, vy } : v2f{ 0.0f, 0.0f };               // zero padding (F.conv2d padding = 5)
+			}
+#pragma unroll
+			for (int t = 0; t < TRIPS; t++)
+			{
+				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
+				if (i < SHH * SW) s_in[ly][lx] = p[t];
+			}
 		}
 		__syncthreads();
 
@@ -160,17 +170,38 @@ namespace fdgs
 		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		for (int i = tid, ly = tid / SW, lx = tid - (tid / SW) * SW; i < SHH * SW; i += STHREADS)
 		{
-			const int gy = y0 + ly - SR, gx = x0 + lx - SR;
-			const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-			const size_t o = plane + (size_t)gy * W + gx;
-			v2f p = { 0.0f, 0.0f };
-			float q = 0.0f;
-			if (in) { p.x = dm_dmu1[o]; p.y = dm_de11[o]; q = dm_de12[o]; }
-			s_p[ly][lx] = p; s_q[ly][lx] = q;
-			ly += STHREADS / SW; lx += STHREADS % SW;
-			if (lx >= SW) { lx -= SW; ly++; }
+			constexpr int TRIPS = (SHH * SW + STHREADS - 1) / STHREADS;
+			v2f p[TRIPS];
+			float q[TRIPS];
+#pragma unroll
+			for (int t = 0; t < TRIPS; t++)       // every load in flight before the first wait
+			{
+				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
+				const int gy = y0 + ly - SR, gx = x0 + lx - SR;
+				const bool in = i < SHH * SW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+				const size_t o = in ? plane + (size_t)gy * W + gx : plane;   // branch-free: outside lanes read a valid address
+				const float va = dm_dmu1[o], vb = dm_de11[o], vc = dm_de12[o];
+				p[t] = in ? v2f{ va, vb } : v2f{ 0.0f, 0.0f };
+				q[t] = in ? vc : 0.0f;
+			}
+#pragma unroll
+			for (int t = 0; t < TRIPS; t++)
+			{
+				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
+				if (i < SHH * SW) { s_p[ly][lx] = p[t]; s_q[ly][lx] = q[t]; }
+			}
+		}
+		// the two pixels this thread finishes below: their image values travel while the windows are computed
+		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * 2;
+		const int gx = x0 + lx;
+		float px[2], py[2];
+#pragma unroll
+		for (int j = 0; j < 2; j++)
+		{
+			const int gy = y0 + ly0 + j;
+			const size_t o = (gx < W && gy < H) ? plane + (size_t)gy * W + gx : plane;
+			px[j] = img1[o]; py[j] = img2[o];
 		}
 		__syncthreads();
 		if (tid < SHH * (STX / 4))
@@ -198,12 +229,10 @@ namespace fdgs
 			*reinterpret_cast<v4f*>(&h_q[ly][cx]) = v4f{ aq[0], aq[1], aq[2], aq[3] };
 		}
 		__syncthreads();
-		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * 2;
 		v2f vp[12];
 		float vq[12];
 #pragma unroll
 		for (int r = 0; r < 12; r++) { vp[r] = h_p[ly0 + r][lx]; vq[r] = h_q[ly0 + r][lx]; }
-		const int gx = x0 + lx;
 		const float up = upstream[0];
 #pragma unroll
 		for (int j = 0; j < 2; j++)
@@ -216,7 +245,7 @@ namespace fdgs
 			if (gx < W && gy < H)
 			{
 				const size_t o = plane + (size_t)gy * W + gx;
-				const float x = img1[o], y = img2[o];
+				const float x = px[j], y = py[j];
 				const float diff = x - y;
 				const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
 				dL_dimg1[o] = up * (w_l1 * sgn + w_ssim * (ab.x + 2.f * x * ab.y + y * d));
