@@ -21,12 +21,12 @@ from . import _capi
 from .fused import raw_backward, raw_forward, raw_preprocess_batch, raw_settings
 from .gaussian_renderer import diff_gaussian_rasterization as _dgr
 from .loss import l1_ssim_grad, l1_ssim_loss
-from .train_host import allreduce_and_step, allreduce_sh_begin, gather_sh_stages_begin
+from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stage_begin
 
 
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
-                 fuse_sh_adam: bool = True, gather_max_views: int = 16, split_colour: bool = False, batch_views: bool = False,
+                 fuse_sh_adam: bool = True, gather_max_views: int = 32, split_colour: bool = False, batch_views: bool = False,
                  sh_group: int = 1):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
@@ -36,7 +36,11 @@ class StepPipeline:
         self.fuse_sh_adam = bool(fuse_sh_adam)
         # several ranks, up to this many views per step over all ranks: the ranks exchange the views' SH stages (32 B per
         # Gaussian and view, all-gather) instead of all-reducing the dense SH gradient (12 M B per Gaussian), and every rank
-        # runs the fused update on all of them (train_host.gather_sh_stages_begin); beyond it the dense all-reduce is cheaper
+        # runs the fused update on all of them.  A view's stage is final when ITS SH backward has run, so its all-gather is
+        # started right there (train_host.gather_view_stage_begin) and travels while the following views are rendered -- the
+        # dense gradient is a sum over the step's views and can only leave at the end.  8 GPUs x 4 views: 4 x 67 MB received
+        # per GPU, three of the four hidden, against a 2 x 7/8 x 171 MB ring all-reduce after the last view; beyond 32 views
+        # the stages outweigh the dense gradient
         self.gather_max_views = int(gather_max_views)
         self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
         # View batching (opt-in, B > 1): the SH coefficients -- 12 M bytes per Gaussian, most of what preprocess and SH backward
@@ -65,6 +69,7 @@ class StepPipeline:
         self._up = {}
         self._gacc = None   # persistent, always-zero blend-backward accumulator (no memset per view)
         self._sh_stage = None   # [B, P, 8]: deferred SH gradient (fdgs_backward_out.sh_stage), flushed once per step
+        self._gathered = None   # [B, world, P, 8]: the stages of all ranks (several ranks, gather mode)
 
     def _upstream(self, B):
         if B not in self._up:
@@ -94,9 +99,12 @@ class StepPipeline:
         if defer_sh and (self._sh_stage is None or self._sh_stage.shape[0] != B or self._sh_stage.shape[1] != m.P):
             with torch.cuda.stream(self.sB):
                 self._sh_stage = torch.empty((B, m.P, 8), dtype=torch.float32, device=self.dev)
+        if gather and (self._gathered is None or self._gathered.shape[0] != B or self._gathered.shape[2] != m.P):
+            with torch.cuda.stream(self.sB):
+                self._gathered = torch.empty((B, self.world, m.P, 8), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
         sh_handle = []
-        sh_gather = []     # gather: (work, stages of all ranks)
+        sh_gather = []     # gather: the work handles of the views' stage exchanges
         sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
         if self.sh_group > 1 and B > 1 and defer_sh:
             return self._step_batched(cams, gts, pipe, bg, scaling_modifier, main, up, fuse, gather, sh_handle, sh_gather, sh_stepped)
@@ -131,9 +139,9 @@ class StepPipeline:
                             self.sF.wait_event(done)
                             self.opt.step_count += 1
                             sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
-                elif b == B - 1 and gather:
-                    def after_sh():   # the stages of this rank are complete: their exchange travels while the geometry backward runs
-                        sh_gather.append(gather_sh_stages_begin(self._sh_stage, self.world))
+                elif gather:
+                    def after_sh(b=b):   # this view's stage is final: its exchange travels while the following views are rendered
+                        sh_gather.append(gather_view_stage_begin(self._sh_stage[b], self._gathered[b]))
                 elif b == B - 1 and ((defer_sh and not fuse) or self.world > 1):
                     def after_sh():
                         if defer_sh:
@@ -180,9 +188,10 @@ class StepPipeline:
                 import torch.distributed as dist
                 feat = m.offsets["_features"][0]
                 geo = dist.all_reduce(m.flat_grad[:feat], op=dist.ReduceOp.SUM, async_op=True)   # 17 floats per Gaussian
-                work, stages = sh_gather[0]
                 self.opt.step_count += 1
-                work.wait()
+                for work in sh_gather:
+                    work.wait()
+                stages = self._gathered.view(-1, m.P, 8)   # [B x world] views: view-major, rank-minor, the same on every rank
                 ok = self.opt.step_sh_staged(stages, rs, _dgr.analytic_sh_gradients())
                 if not ok:   # layout the fused kernel does not take: every rank builds the same summed dL_dsh from all the stages
                     _capi.sh_flush(stages, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim, rs.force_sh_3d,
@@ -204,7 +213,8 @@ class StepPipeline:
                 self.opt.step_count += 1
                 sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
         elif gather:
-            sh_gather.append(gather_sh_stages_begin(self._sh_stage, self.world))
+            for b in range(self._sh_stage.shape[0]):
+                sh_gather.append(gather_view_stage_begin(self._sh_stage[b], self._gathered[b]))
         elif (defer_sh and not fuse) or self.world > 1:
             if defer_sh:
                 _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,

@@ -398,6 +398,21 @@ def gather_sh_stages_begin(stages: torch.Tensor, world_size: int):
     return dist.all_reduce(gathered, op=dist.ReduceOp.SUM, async_op=True), gathered
 
 
+def gather_view_stage_begin(stage: torch.Tensor, out: torch.Tensor):
+    """The exchange of ONE view's staged SH gradient, started as soon as that view's SH backward has been enqueued: ``stage``
+    [P, 8] of this rank -> ``out`` [world, P, 8] (rank-major, the same on every rank).  Returns the work handle.
+
+    Per view instead of once per step (gather_sh_stages_begin): a view's 32 bytes per Gaussian are final when ITS SH backward
+    has run, so the all-gather of view b travels over xGMI while views b+1.. are rendered; only the last view's exchange is
+    left at the end of the step.  (The dense gradient cannot do that: it is the SUM over the step's views.)"""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" and hasattr(dist, "all_gather_into_tensor"):
+        return dist.all_gather_into_tensor(out, stage.contiguous(), async_op=True)
+    out.zero_()
+    out[dist.get_rank()].copy_(stage)
+    return dist.all_reduce(out, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: int, chunks: int = 4, average: bool = False,
                        sh_handle=None) -> None:
     """Gradient all-reduce + Adam with the two overlapped: the bucket is cut into pieces, all all-reduces are issued

@@ -11,9 +11,10 @@ per view:
 then once per step the optimizer step (Adam, torch.optim.Adam arithmetic):
     N = 1: the SH coefficients (89 % of the parameters) are updated straight from the views' staged SH gradients by one fused
            kernel (fdgs_adam_step_sh), the 17 geometry floats per Gaussian by fdgs_adam_step;
-    N > 1: the exchange over RCCL first -- up to 16 views per step over all ranks: all-gather of the views' SH stages (32 B per
-           Gaussian and view) + all-reduce of the geometry gradients, then the same fused update on every rank; more views:
-           all-reduce of the flat 161*P-float gradient bucket, then Adam over it (--dense-sh-exchange forces this).
+    N > 1: the exchange over RCCL -- up to 32 views per step over all ranks: every view's SH stage (32 B per Gaussian) is
+           all-gathered as soon as its SH backward has run, i.e. while the following views are rendered, + all-reduce of the
+           geometry gradients at the end, then the same fused update on every rank; more views: all-reduce of the flat
+           161*P-float gradient bucket, then Adam over it (--dense-sh-exchange forces this).
 Frames / timesteps shard embarrassingly: rank r renders timestamp (r + 0.5) / N of the sequence with
 replicated parameters (scaling = "weak": B views per GPU per step).  Inputs are synthetic
 (fdgs.synth, seed 0) and resident in HBM before the timed region.
@@ -106,7 +107,7 @@ def parse_args():
                          "forward-only loop (default), also in the training step, or nowhere")
     ap.add_argument("--dense-sh-exchange", action="store_true",
                     help="N > 1: always all-reduce the dense SH gradient (default: up to 16 views per step over all ranks exchange "
-                         "the views' 32-byte SH stages by all-gather instead, train_host.gather_sh_stages_begin)")
+                         "the views' 32-byte SH stages by all-gather instead, train_host.gather_view_stage_begin)")
     return ap.parse_args()
 
 
@@ -331,7 +332,7 @@ def main():
     if use_pipeline:
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
-                                gather_max_views=0 if args.dense_sh_exchange else 16, split_colour=args.split_colour == "all",
+                                gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all",
                                 batch_views=args.batch_views, sh_group=args.sh_group)
 
     def step():
@@ -364,7 +365,7 @@ def main():
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.
     if use_pipeline:
         stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
-                                  gather_max_views=0 if args.dense_sh_exchange else 16, batch_views=args.batch_views, sh_group=args.sh_group)
+                                  gather_max_views=0 if args.dense_sh_exchange else 32, batch_views=args.batch_views, sh_group=args.sh_group)
         stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)  # noqa: E731
     else:
         stage_step = step

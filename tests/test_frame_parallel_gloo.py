@@ -94,6 +94,13 @@ def _worker(rank, world, port, q):
     work.wait()
     want = torch.cat([torch.randn(B, P, 8, generator=torch.Generator().manual_seed(500 + r)) for r in range(world)])
     assert stages.shape == (world * B, P, 8) and torch.equal(stages, want)
+    # ... and view by view (the step pipeline starts a view's exchange right behind its SH backward): [B, world, P, 8]
+    gathered = torch.empty(B, world, P, 8)
+    works = [train_host.gather_view_stage_begin(mine[b], gathered[b]) for b in range(B)]
+    for w in works:
+        w.wait()
+    for r in range(world):
+        assert torch.equal(gathered[:, r], want[r * B:(r + 1) * B])
     q.put((rank, float(model.flat.detach().abs().sum())))
     dist.destroy_process_group()
 

@@ -1,18 +1,24 @@
-"""Timing of the fused L1+SSIM kernels alone (dev tool)."""
-import sys, os, time
+#!/usr/bin/env python3
+"""Times the fused L1 + SSIM kernels on their own (HIP events, current stream): forward+backward pair per call.
+   python tools/ssim_time.py [H W]"""
+import sys, os, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from fdgs.loss import l1_ssim_value_and_grad
+loss = importlib.import_module("4d-gaussian-splatting_amd.loss")
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1014, 1352)
 dev = torch.device("cuda:0")
-H, W = (int(sys.argv[2]), int(sys.argv[1])) if len(sys.argv) > 2 else (1014, 1352)
-n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-g = torch.Generator(device="cpu").manual_seed(0)
-a = torch.rand(3, H, W, generator=g).to(dev); b = torch.rand(3, H, W, generator=g).to(dev)
+g = torch.Generator(device=dev).manual_seed(1)
+img = torch.rand((3, H, W), device=dev, generator=g)
+gt = torch.rand((3, H, W), device=dev, generator=g)
 up = torch.ones(1, device=dev)
-for _ in range(5):
-    l1_ssim_value_and_grad(a, b, 0.2, up)
-torch.cuda.synchronize(); t0 = time.time()
-for _ in range(n):
-    l1_ssim_value_and_grad(a, b, 0.2, up)
+for _ in range(20):
+    loss.l1_ssim_grad(img, gt, 0.2, up)
 torch.cuda.synchronize()
-print("l1+ssim fwd+bwd %dx%d: %.1f us per call" % (W, H, (time.time() - t0) / n * 1e6))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 200
+e0.record()
+for _ in range(n):
+    loss.l1_ssim_grad(img, gt, 0.2, up)
+e1.record()
+torch.cuda.synchronize()
+print("l1_ssim forward + backward: %.1f us per image (%dx%d)" % (e0.elapsed_time(e1) / n * 1e3, W, H))
