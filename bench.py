@@ -85,7 +85,7 @@ def parse_args():
                          "reference's PyTorch loss: what a user of the reference gets by swapping one import (0 = skip)")
     ap.add_argument("--spatial-order", action="store_true",
                     help="analysis: the whole run on the Morton-ordered model (train_host.spatial_sort before the warm-up); noted in config.workload")
-    ap.add_argument("--spatial-order-steps", type=int, default=10,
+    ap.add_argument("--spatial-order-steps", type=int, default=20,
                     help="steps of the extra leg that re-times the step with the model stored in Morton order of the Gaussians' "
                          "positions (train_host.spatial_sort -- what fdgs.harness.train keeps after every densification) instead of the "
                          "generator's random order: spatial_order_images_s / spatial_order_forward_ms (0 = skip)")
