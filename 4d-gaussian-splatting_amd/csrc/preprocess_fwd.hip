@@ -35,6 +35,7 @@ namespace fdgs
 		float scale_modifier, prefilter_var, tan_fovx, tan_fovy, focal_x, focal_y, timestamp, time_duration;
 		int rot_4d, gaussian_dim, force_sh_3d, raw, sh_vec_ok;
 		int grid_x, grid_y;
+		int tile_cull;   // fdgs_forward_out.tile_cull: list the Gaussian only in the tiles it can reach with alpha >= 1/255
 		// outputs
 		int32_t* radii; float* out_means3D; float* covs_com;
 		float4* records; float* depths; float* cov3D; uint32_t* tiles_touched; ushort4* rect; uint8_t* clamped;
@@ -181,6 +182,34 @@ namespace fdgs
 		else stage_sh_block_scalar(tile, shs, g0, P, M, first_coeff, ncoeff, alive_mask, lane);
 	}
 
+	// fdgs_forward_out.tile_cull: the tiles of the reference's rectangle (the square of 3 sigma_max around the mean,
+	// auxiliary.h:46-57) that the Gaussian can actually reach.  alpha = min(0.99, opacity * exp(-q(d))) with q(d) = 0.5 d^T K d,
+	// K = the conic AS STORED (fp32), passes the blend's test alpha >= 1/255 (forward.cu:590) only where q(d) <= ln(255 opacity).
+	// The ellipse q <= tau has the axis-aligned extents |dx| <= sqrt(2 tau S_xx), |dy| <= sqrt(2 tau S_yy), S = K^-1.  K is the
+	// rounded (cz, -cy, cx) / det with det = cx cz - cy^2 as fp32 computed it, so S = (cx, cy, cz) * det / D with D the EXACT
+	// determinant of the fp32 numbers (in double: an elongated splat cancels most of det's bits, and S with them).  Slack: 0.05 in
+	// tau (5 % in alpha, as the blend kernels' block test: covers every rounding of the per-pixel evaluation), 0.1 % + half a
+	// pixel on the extents.  Opacity below 1/255: alpha < 1/255 everywhere, listed nowhere.  Anything odd: the reference's rectangle.
+	__device__ __forceinline__ ushort4 reachable_rect(const ushort4 ref, const float2 pix, const float3 conic, const float opacity,
+	                                                  const float cx, const float cy, const float cz, const float det)
+	{
+		if (opacity < 1.0f / 255.0f) return make_ushort4(0, 0, 0, 0);
+		if (!(conic.x > 0.0f && conic.z > 0.0f)) return ref;
+		const double D = (double)cx * (double)cz - (double)cy * (double)cy;
+		if (!(D > 0.0) || !(det > 0.0f)) return ref;
+		const float ratio = (float)((double)det / D);
+		const float tau2 = 2.0f * (logf(255.0f * opacity) + 0.05f);
+		const float hx = sqrtf(tau2 * cx * ratio) * 1.001f + 0.5f, hy = sqrtf(tau2 * cz * ratio) * 1.001f + 0.5f;
+		if (!(hx < 1.0e6f && hy < 1.0e6f)) return ref;   // also NaN
+		// tile t holds the pixel centres TILE * t .. TILE * t + TILE - 1: those with a centre inside [pix - h, pix + h]
+		const int tx0 = max((int)ref.x, (int)ceilf((pix.x - hx - (float)(TILE_X - 1)) / (float)TILE_X));
+		const int tx1 = min((int)ref.z, (int)floorf((pix.x + hx) / (float)TILE_X) + 1);
+		const int ty0 = max((int)ref.y, (int)ceilf((pix.y - hy - (float)(TILE_Y - 1)) / (float)TILE_Y));
+		const int ty1 = min((int)ref.w, (int)floorf((pix.y + hy) / (float)TILE_Y) + 1);
+		if (tx1 <= tx0 || ty1 <= ty0) return make_ushort4(0, 0, 0, 0);
+		return make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
+	}
+
 	// PART 0: everything.  The forward can also run it in two launches (fdgs_forward_out.split_colour): PART 1 = the geometry
 	// (everything the tile binning needs; colour left at zero), PART 2 = the SH colour of the Gaussians PART 1 kept (radius > 0),
 	// on a second stream next to the binning -- same arithmetic, same results.
@@ -323,9 +352,10 @@ namespace fdgs
 					else
 					{
 						radius = r;
-						tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+						tiles = (uint32_t)((y1 - y0) * (x1 - x0));   // the reference's count, whatever the lists hold
 						rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
 						depth = p_view.z;
+						if (a.tile_cull) rect = reachable_rect(rect, pix, conic, opacity, cx, cy, cz, det);
 					}
 				}
 			}
@@ -434,6 +464,7 @@ namespace fdgs
 		a.rot_4d = s.rot_4d; a.gaussian_dim = s.gaussian_dim; a.force_sh_3d = s.force_sh_3d; a.raw = s.raw_params;
 		a.sh_vec_ok = (s.shs != nullptr && (reinterpret_cast<uintptr_t>(s.shs) & 15) == 0 && (3 * s.M) % 4 == 0) ? 1 : 0;
 		a.grid_x = div_up(s.W, TILE_X); a.grid_y = div_up(s.H, TILE_Y);
+		a.tile_cull = out.tile_cull != 0 ? 1 : 0;
 		a.radii = out.radii; a.out_means3D = out.out_means3D; a.covs_com = out.covs_com;
 		a.records = reinterpret_cast<float4*>(geom + L.records);
 		a.depths = reinterpret_cast<float*>(geom + L.depths);

@@ -31,19 +31,20 @@ def _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_r
 
 
 def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
-                split_colour=False, preprocessed=None):
+                split_colour=False, preprocessed=None, tile_cull=False):
     """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple.
-    ``preprocessed``: the view's handle from ``raw_preprocess_batch``."""
+    ``preprocessed``: the view's handle from ``raw_preprocess_batch``; ``tile_cull``: fdgs_forward_out.tile_cull."""
     args = _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
-    return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour, preprocessed=preprocessed)
+    return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour, preprocessed=preprocessed, tile_cull=tile_cull)
 
 
-def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var):
+def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
+                         tile_cull=False):
     """View-batched preprocess on RAW parameters (fdgs_preprocess_batch): ``settings`` = the views' raster settings (the views of
     one optimizer step share every parameter tensor).  One handle per view for ``raw_forward(..., preprocessed=handle)``."""
     views = [_raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
              for rs in settings]
-    return _C.preprocess_batch(views, raw_params=True)
+    return _C.preprocess_batch(views, raw_params=True, tile_cull=tile_cull)
 
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
@@ -87,10 +88,10 @@ def raw_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0):
 class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
-                prefilter_var, raster_settings, grad_sink, accumulate):
+                prefilter_var, raster_settings, grad_sink, accumulate, tile_cull=False):
         rs = raster_settings
         (R, color, flow, depth, T, radii, geom, binb, img, covs_com, out_means3D) = raw_forward(
-            rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
+            rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var, tile_cull=tile_cull)
         ctx.rs, ctx.R, ctx.prefilter_var, ctx.sink, ctx.accumulate = rs, R, prefilter_var, grad_sink, bool(accumulate)
         ctx.save_for_backward(means3D, out_means3D, scaling_raw, rotation_raw, radii, sh, opacity_raw, ts, scaling_t_raw,
                               rotation_r_raw, geom, binb, img)
@@ -120,16 +121,17 @@ class _RasterizeRaw(torch.autograd.Function):
                 ret("dL_dopacity", opacity_raw, d_opacity), ret("dL_dts", ts, d_ts),
                 ret("dL_dscales", scaling_raw, d_scales), ret("dL_dscales_t", scaling_t_raw, d_scales_t),
                 ret("dL_drotations", rotation_raw, d_rot), ret("dL_drotations_r", rotation_r_raw, d_rot_r),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def render_raw(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, grad_sink=None, accumulate=False):
-    """``render()`` with the activations fused into the kernels; see the module docstring."""
+def render_raw(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, grad_sink=None, accumulate=False, tile_cull=False):
+    """``render()`` with the activations fused into the kernels; see the module docstring.  ``tile_cull``:
+    fdgs_forward_out.tile_cull (shorter tile lists, same pixels and gradients)."""
     rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
         viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     screenspace_points = torch.zeros_like(xyz, requires_grad=True)
     color, radii, depth, alpha, flow = _RasterizeRaw.apply(
         xyz, screenspace_points, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r,
-        prefilter_var, rs, grad_sink, accumulate)
+        prefilter_var, rs, grad_sink, accumulate, tile_cull)
     return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth": depth, "alpha": alpha, "flow": flow}

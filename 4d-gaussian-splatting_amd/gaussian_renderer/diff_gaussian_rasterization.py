@@ -117,11 +117,14 @@ class _NativeRasterizer:
     def rasterize_gaussians(self, bg, means3D, colors, flows, opacity, ts, scales, scales_t, rotations, rotations_r,
                             scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
-                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False, preprocessed=None):
+                            gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False, preprocessed=None,
+                            tile_cull=False):
         """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49).
         Keyword-only extensions: ``raw_params``: the scale / opacity / rotation tensors are the model's raw
         parameters and the kernels apply the activations (fdgs_scene.raw_params); ``split_colour``: the SH colour evaluation
-        runs on the library's second stream next to the tile binning (fdgs_forward_out.split_colour; forward-only rendering)."""
+        runs on the library's second stream next to the tile binning (fdgs_forward_out.split_colour; forward-only rendering);
+        ``tile_cull``: a Gaussian is only listed in the tiles it can reach with alpha >= 1/255 (fdgs_forward_out.tile_cull: same
+        pixels and gradients, shorter tile lists)."""
         if not means3D.is_cuda:
             raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
         dev = means3D.device
@@ -150,7 +153,8 @@ class _NativeRasterizer:
             scratch = _Scratch(dev)
         out = _capi.FdgsForwardOut(out_color.data_ptr(), out_flow.data_ptr(), out_depth.data_ptr(), out_T.data_ptr(),
                                    _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com),
-                                   int(preprocessed is not None), int(bool(split_colour)))
+                                   int(preprocessed is not None), int(bool(split_colour)),
+                                   int(preprocessed["tile_cull"] if preprocessed is not None else bool(tile_cull)))
         R = C.c_int32(0)
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), scratch.callback, None,
@@ -160,7 +164,7 @@ class _NativeRasterizer:
         del keep
         return (int(R.value), out_color, out_flow, out_depth, out_T, radii, geom, binb, img, covs_com, out_means3D)
 
-    def preprocess_batch(self, views, *, raw_params=False):
+    def preprocess_batch(self, views, *, raw_params=False, tile_cull=False):
         """View-batched preprocess (fdgs_preprocess_batch): ``views`` = the 30-tuples of positional arguments of
         ``rasterize_gaussians`` for the views of ONE optimizer step (same Gaussian tensors, own camera / timestamp).  The
         geometry runs per view, the SH colours of all views in one pass over the coefficients.  Returns one handle per view;
@@ -174,10 +178,11 @@ class _NativeRasterizer:
             P = scene.P
             fo = dict(dtype=torch.float32, device=dev)
             h = {"scene": scene, "keep": keep, "radii": torch.empty((P,), dtype=torch.int32, device=dev),
-                 "out_means3D": torch.empty((P, 3), **fo), "covs_com": torch.empty((P, 6), **fo), "scratch": _Scratch(dev)}
+                 "out_means3D": torch.empty((P, 3), **fo), "covs_com": torch.empty((P, 6), **fo), "scratch": _Scratch(dev),
+                 "tile_cull": bool(tile_cull)}
             h["scratch"].reuse = True
             h["out"] = _capi.FdgsForwardOut(None, None, None, None, _capi._ptr(h["radii"]), _capi._ptr(h["out_means3D"]),
-                                            _capi._ptr(h["covs_com"]), 0, 0)
+                                            _capi._ptr(h["covs_com"]), 0, 0, int(bool(tile_cull)))
             handles.append(h)
         B = len(handles)
         scenes = (C.POINTER(_capi.FdgsScene) * B)(*[C.pointer(h["scene"]) for h in handles])

@@ -27,7 +27,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stag
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
                  fuse_sh_adam: bool = True, gather_max_views: int = 32, split_colour: bool = False, batch_views: bool = False,
-                 sh_group: int = 1):
+                 sh_group: int = 1, tile_cull: bool = True):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -42,6 +42,9 @@ class StepPipeline:
         # per GPU, three of the four hidden, against a 2 x 7/8 x 171 MB ring all-reduce after the last view; beyond 32 views
         # the stages outweigh the dense gradient
         self.gather_max_views = int(gather_max_views)
+        # fdgs_forward_out.tile_cull: the tile lists hold a Gaussian only where it can reach alpha >= 1/255 (same pixels and
+        # gradients as with the reference's lists, a quarter fewer instances at C3)
+        self.tile_cull = bool(tile_cull)
         self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
         # View batching (opt-in, B > 1): the SH coefficients -- 12 M bytes per Gaussian, most of what preprocess and SH backward
         # read -- are the same for every view of the step.  ``batch_views``: the views' geometry still runs per view, but their SH
@@ -113,14 +116,14 @@ class StepPipeline:
             # the SH colours of all views in one pass over the coefficients, ahead of the first view's binning
             with torch.cuda.stream(self.sF):
                 sets = [raw_settings(c, m, pipe, bg, scaling_modifier) for c in cams]
-                handles = raw_preprocess_batch([s_[0] for s_ in sets], *sets[0][1])
+                handles = raw_preprocess_batch([s_[0] for s_ in sets], *sets[0][1], tile_cull=self.tile_cull)
         for b in range(B):
             with torch.cuda.stream(self.sF):
                 rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = raw_settings(
                     cams[b], m, pipe, bg, scaling_modifier)
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
                     rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
-                    split_colour=self.split_colour and handles[b] is None)
+                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
@@ -239,13 +242,14 @@ class StepPipeline:
             (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var) = sets[0][1]
             handles = [None] * B
             if self.batch_views:
-                handles = raw_preprocess_batch([s[0] for s in sets], xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var)
+                handles = raw_preprocess_batch([s[0] for s in sets], xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var,
+                                               tile_cull=self.tile_cull)
         for b in range(B):
             rs = sets[b][0]
             with torch.cuda.stream(self.sF):
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
                     rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
-                    split_colour=self.split_colour and handles[b] is None)
+                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):

@@ -105,6 +105,9 @@ def parse_args():
     ap.add_argument("--split-colour", choices=("forward", "all", "off"), default="forward",
                     help="fdgs_forward_out.split_colour (SH colours on the library's second stream next to the binning): in the "
                          "forward-only loop (default), also in the training step, or nowhere")
+    ap.add_argument("--no-tile-cull", action="store_true",
+                    help="A/B: the reference's tile lists (every tile of the 3-sigma square) instead of fdgs_forward_out.tile_cull "
+                         "(a Gaussian listed only where it can reach alpha >= 1/255: same pixels and gradients)")
     ap.add_argument("--dense-sh-exchange", action="store_true",
                     help="N > 1: always all-reduce the dense SH gradient (default: up to 16 views per step over all ranks exchange "
                          "the views' 32-byte SH stages by all-gather instead, train_host.gather_view_stage_begin)")
@@ -332,7 +335,7 @@ def main():
     if use_pipeline:
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
-                                gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all",
+                                gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all", tile_cull=not args.no_tile_cull,
                                 batch_views=args.batch_views, sh_group=args.sh_group)
 
     def step():
@@ -365,7 +368,8 @@ def main():
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.
     if use_pipeline:
         stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
-                                  gather_max_views=0 if args.dense_sh_exchange else 32, batch_views=args.batch_views, sh_group=args.sh_group)
+                                  gather_max_views=0 if args.dense_sh_exchange else 32, batch_views=args.batch_views, sh_group=args.sh_group,
+                                  tile_cull=not args.no_tile_cull)
         stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)  # noqa: E731
     else:
         stage_step = step
@@ -444,7 +448,7 @@ def main():
             from fdgs.fused import raw_forward, raw_settings
             rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
             return raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
-                               split_colour=args.split_colour != "off")
+                               split_colour=args.split_colour != "off", tile_cull=not args.no_tile_cull)
         return render(c, model, pipe, bg) if args.reference_host else render_raw(c, model, pipe, bg)
 
     with torch.no_grad():
@@ -470,7 +474,8 @@ def main():
         def raster_only(c):
             rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
             (R, color, flow, depth, T, radii, geom, binb, img, _c, om) = raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t,
-                                                                                    rotation, rotation_r, pv)
+                                                                                    rotation, rotation_r, pv,
+                                                                                    tile_cull=not args.no_tile_cull)
             raw_backward(rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img,
                          up4["grad_color"], up4["grad_depth"], up4["grad_alpha"], up4["grad_flow"], sink4, False, grad_accum=gacc)
 
@@ -599,7 +604,7 @@ def main():
         "config": {"workload": ("[model stored in Morton order] " if args.spatial_order else "") + "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
                                                                         M, cfg.rot_4d, B, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else (", fused activations, explicit fwd/loss/bwd on %s" % ("one stream" if args.no_overlap else "two HIP streams") if use_pipeline else ", fused activations, autograd")),
-                   "num_rendered": int(round(R_timed)), "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,
+                   "num_rendered": int(round(R_timed)), "tile_cull": not args.no_tile_cull, "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,
                    "parallelism": "frame-parallel dp%d" % world, "mode": mode},
         "forward_mpix_s": round(world * n_fwd * N / dt_fwd / 1e6, 1),
         "forward_split_colour": bool(use_pipeline and args.split_colour != "off"),

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 300 /* 0.3.0.  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+#define FDGS_VERSION 310 /* 0.3.0.  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
                             (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
                             FDGS_VERSION: a binding built against another revision of this header is turned away instead of
                             having the library read past the end of a shorter struct. */
@@ -141,6 +141,15 @@ typedef struct fdgs_forward_out
 	                         memory traffic, which only the blend needs) on an internal second stream next to the tile binning
 	                         (events in and out): shortens the forward's critical path by ~30 us at C3 for forward-only
 	                         rendering; same arithmetic, bit-identical outputs */
+	int32_t tile_cull;    /* 0: the tile lists are the reference's -- every tile of the square of 3 sigma_max around the projected
+	                         mean (auxiliary.h:46-57), bit-identical point_list / ranges / n_contrib.  1: a Gaussian is only listed
+	                         in the tiles of the axis-aligned bounding box of the region where it can reach alpha >= 1/255 (the
+	                         forward blend's own per-pixel test, forward.cu:590), intersected with the reference's square; a
+	                         Gaussian whose opacity is below 1/255 is listed nowhere.  Every (Gaussian, tile) instance left out
+	                         fails that test on every pixel of the tile, so the pixels, radii and gradients are the reference's
+	                         (to fp32 rounding: the blend kernels pair the list entries differently); num_rendered, the
+	                         lists and n_contrib (a list position) are not: a quarter fewer instances at C3.  The backward takes
+	                         whatever lists the forward left */
 } fdgs_forward_out;
 
 /* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output

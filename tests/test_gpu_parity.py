@@ -125,7 +125,7 @@ def test_depth_only_backward_vs_oracle(gpu_device):
 # The configuration the metric is quoted on, through the path bench.py times
 # ----------------------------------------------------------------------------------------------------------------
 
-def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border):
+def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
     """The calls fdgs/pipeline.py::StepPipeline makes for one optimizer step -- raw parameters (activations fused into
     the kernels, fdgs_scene.raw_params = 1), fused L1 + SSIM gradient as the only upstream gradient (colour-only blend
     backward), parameter gradients accumulated over the views into the flat bucket, persistent always-zero blend
@@ -133,7 +133,9 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border):
     derive themselves (fdgs_debug_activations: same device functions, bit-identical), and its gradients are pulled
     back to the raw parameters in float64, so the 1e-4 bar applies to this mode unchanged.
     Bar: radii / tiles_touched / depth bits / point_list / sorted tile ids / ranges bit-exact, n_contrib equal and
-    pixels <= 1e-4 abs off the flagged cliff pixels, every gradient <= 1e-4 * max(1, max|ref|)."""
+    pixels <= 1e-4 abs off the flagged cliff pixels, every gradient <= 1e-4 * max(1, max|ref|).
+    ``tile_cull`` (what StepPipeline runs with): the lists are the reference's with the instances taken out that cannot reach
+    alpha >= 1/255 in their tile -- checked as such (util.check_culled_lists) instead of bit for bit."""
     from fdgs import _capi, train_host
     from fdgs.fused import raw_backward, raw_forward, raw_settings
     from fdgs.loss import l1_ssim_grad
@@ -179,7 +181,7 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border):
     total = None
     for b, cam in enumerate(cams):
         rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(cam, model, pipe, bg)
-        res = raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv)
+        res = raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, tile_cull=tile_cull)
         (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = res
         hip = collect_forward(res, P, W, H)
         g_color, _handle = l1_ssim_grad(color, gts[b], 0.2, up)
@@ -219,7 +221,9 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border):
         gc = g_color.cpu()
         refg = dict(o.backward(gc, torch.zeros(1, H, W), torch.zeros(1, H, W), torch.zeros(2, H, W)))
         o.close()
-        rep = check_forward(hip, ref, "%s view %d" % (label, b), max_border=max_border)
+        rep = check_forward(hip, ref, "%s view %d" % (label, b), max_border=max_border, tile_cull=tile_cull, WH=(W, H))
+        if tile_cull:
+            print("%s view %d: instances listed: %s" % (label, b, rep["instances"]))
         print("%s view %d: R %d, cliff pixel fraction %.2e (upstream gradient zeroed there), max abs pixel err colour %.2e depth %.2e T %.2e" % (
             label, b, ref["R"], rep["border_frac"], rep["out_color"], rep["out_depth"], rep["out_T"]))
         # per-view outputs of the backward (always overwritten): viewspace gradient, colour, covariance
@@ -256,15 +260,18 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border):
     print("%s accumulated raw-parameter gradients over %d views (max abs err / max|ref|):" % (label, n_views), line)
 
 
-def test_timed_path_small_vs_oracle(gpu_device):
-    """The timed path (see _timed_path_vs_oracle) on a small scene."""
-    _timed_path_vs_oracle(SC("v", 30000, 400, 304, 3, 2, 0.015, 10.0, True, 4, False), gpu_device, 2, "timed-small", 1e-3)
+@pytest.mark.parametrize("tile_cull", [False, True])
+def test_timed_path_small_vs_oracle(tile_cull, gpu_device):
+    """The timed path (see _timed_path_vs_oracle) on a small scene, with the reference's lists and with tile_cull."""
+    _timed_path_vs_oracle(SC("v", 30000, 400, 304, 3, 2, 0.015, 10.0, True, 4, False), gpu_device, 2, "timed-small", 1e-3, tile_cull=tile_cull)
 
 
-def test_c3_full_size_vs_oracle(gpu_device):
+@pytest.mark.parametrize("tile_cull", [True, False])
+def test_c3_full_size_vs_oracle(tile_cull, gpu_device):
     """BASELINE configs[2] -- the configuration the metric is quoted on (300 k Gaussians, 1352x1014, M = 48) -- at
-    FULL size through the path bench.py times, 2 views accumulated, against the port oracle."""
-    _timed_path_vs_oracle(synth.CONFIGS["C3"], gpu_device, 2, "C3", 1e-3)
+    FULL size through the path bench.py times (tile_cull = True; and with the reference's lists, bit for bit), 2 views
+    accumulated, against the port oracle."""
+    _timed_path_vs_oracle(synth.CONFIGS["C3"], gpu_device, 2, "C3", 1e-3, tile_cull=tile_cull)
 
 
 def test_c5_full_size_forward_backward_vs_oracle(gpu_device):

@@ -1,0 +1,101 @@
+"""fdgs_forward_out.tile_cull: a Gaussian is listed only in the tiles of the bounding box of the region where it can reach
+alpha >= 1/255 (csrc/preprocess_fwd.hip, reachable_rect) instead of every tile of the 3-sigma square (auxiliary.h:46-57).
+
+What must hold, and is checked here against the oracle (reference lists) and against the same forward without the flag:
+  * the lists are the reference's lists with instances taken out, order kept; every instance taken out fails the blend's
+    per-pixel test on every pixel of its tile in the oracle's own arithmetic; n_contrib points at the same instance;
+  * radii, tiles_touched, depth bits, means2D, colours, covariances: bit-identical to the forward without the flag;
+  * pixels: <= 1e-4 abs against the oracle (the bar of every parity test) and <= 2e-6 against the forward without the flag
+    (the blend kernels pair the entries of the shorter list differently: fp32 association only), T bit-identical;
+  * gradients: the parity bar against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import GRAD_SCALE, check_backward, check_forward, run_hip, run_oracle, synth
+
+pytestmark = pytest.mark.gpu
+
+SC = synth.SceneConfig
+
+
+def _adversarial(P=12000, W=400, H=304, seed=11):
+    """Splats that stress the bound: needle-shaped (axis ratios up to 1:60) at every orientation -- full random rotations,
+    also the 4D ones --, opacities from well below 1/255 to 1, sizes from sub-pixel to a third of the image, means up to
+    half an image outside the frame."""
+    scene = synth.make_scene(SC("adv", P, W, H, 2, 1, 0.02, 2.0, True, 4, False), seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)    # noqa: E731
+    n = lambda *s: torch.randn(*s, generator=g)   # noqa: E731
+    base = 0.004 * torch.exp(3.5 * r(P, 1))                          # 0.004 .. 0.13 scene units
+    ratio = torch.exp(-4.1 * r(P, 3) * (r(P, 3) < 0.6))              # most axes squeezed by up to 60x
+    scene["scales"] = (base * ratio).float()
+    q = n(P, 4); scene["rotations"] = (q / q.norm(dim=1, keepdim=True)).float()
+    q = n(P, 4); scene["rotations_r"] = (q / q.norm(dim=1, keepdim=True)).float()
+    scene["opacities"] = torch.exp(-7.0 * r(P, 1) ** 2).float().clamp(max=0.999)   # down to 9e-4: below 1/255 for a tenth of them
+    scene["means3D"] = (scene["means3D"] * torch.tensor([1.6, 1.6, 1.0])).float()
+    return scene
+
+
+CASES = {
+    "C1": lambda: synth.make_scene(synth.CONFIGS["C1"], seed=0, random_flow=True, bg=(0.3, 0.5, 0.7)),
+    "rot4d_sh3_t2": lambda: synth.make_scene(SC("v", 30000, 400, 304, 3, 2, 0.015, 10.0, True, 4, False), seed=3, random_flow=True),
+    "dim3_sh2": lambda: synth.make_scene(SC("v", 8000, 256, 256, 2, 0, 0.03, 1.0, False, 3, False), seed=3, random_flow=True),
+    "ragged_33x17": lambda: synth.make_scene(SC("v", 500, 33, 17, 3, 0, 0.05, 1.0, True, 4, True), seed=3),
+    "adversarial": _adversarial,
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_tile_cull_vs_oracle_and_vs_reference_lists(name, gpu_device):
+    scene = CASES[name]()
+    W, H = scene["W"], scene["H"]
+    grads = synth.make_upstream_grads(W, H, seed=1, scale=GRAD_SCALE)
+    ref, refg = run_oracle(scene, grads, kind="port")
+    keep = torch.from_numpy(~ref["border"].astype(bool)).to(torch.float32)      # cliff pixels: no upstream gradient, both sides
+    grads = {k: v * keep.reshape((1,) * (v.dim() - 2) + (H, W)) for k, v in grads.items()}
+    ref, refg = run_oracle(scene, grads, kind="port")
+    full, fullg = run_hip(scene, gpu_device, grads)
+    cull, cullg = run_hip(scene, gpu_device, grads, tile_cull=True)
+    # against the oracle: lists (as sub-lists), pixels, gradients
+    adv = name == "adversarial"   # hundreds of overlapping needles per pixel, depth image up to ~8: bar relative to the output's scale
+    check_forward(full, ref, name + " (reference lists)", max_border=5e-3, pix_rel=adv)
+    rep = check_forward(cull, ref, name, tile_cull=True, WH=(W, H), max_border=5e-3, pix_rel=adv)
+    # gradients against the oracle -- except for the needles: 1:60 splats make dL/dcov3D a cancelling sum (denominators
+    # ~ det^2, backward.cu:560-575) that two fp32 implementations agree on to 1e-2 only, whatever the lists; there the
+    # comparison that says something is the one with the backward on the reference's lists, below
+    repg = {} if adv else check_backward(cullg, refg, name)
+    print(name, "instances kept", rep["instances"], {k: ("%.2e" % v if isinstance(v, float) else v) for k, v in rep.items() if k != "instances"})
+    print(name, {k: "%.2e/%.1e" % v for k, v in repg.items()})
+    assert cull["R"] <= full["R"] == ref["R"]
+    # against the forward without the flag
+    for k in ("radii", "tiles_touched", "depths", "means2D", "conic_opacity", "rgb", "cov3D", "out_means3D", "clamped", "out_T", "final_T"):
+        assert np.array_equal(cull[k], full[k], equal_nan=True), "%s: %s changes with tile_cull" % (name, k)
+    for k in ("out_color", "out_depth", "out_flow"):
+        d = float(np.abs(cull[k] - full[k]).max())
+        assert d <= 2e-6 * max(1.0, float(np.abs(full[k]).max())), "%s: %s differs by %g from the forward without tile_cull" % (name, k, d)
+    # needles: everything behind the blend backward's own outputs amplifies the float atomics' arrival order -- two runs of the SAME
+    # backward differ by 3e-4 (dL_dmean3D) .. 1.5e-2 (dL_dscale_t) of the scale there, with or without the flag (measured) -- so
+    # only the blend-level gradients are compared for them
+    blend_level = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dsh", "dL_dflows")
+    for k in fullg:
+        if adv and k not in blend_level:
+            continue
+        sc = max(1.0, float(np.abs(fullg[k]).max()))
+        d = float(np.abs(cullg[k] - fullg[k]).max())
+        assert d <= 2e-5 * sc, "%s: gradient %s differs by %g (scale %g) from the backward on the reference's lists" % (name, k, d, sc)
+
+
+def test_tile_cull_drops_what_cannot_contribute(gpu_device):
+    """The flag must actually shorten the lists where the reference's square is mostly empty: needles and faint splats."""
+    scene = _adversarial()
+    full, _ = run_hip(scene, gpu_device, None)
+    cull, _ = run_hip(scene, gpu_device, None, tile_cull=True)
+    print("adversarial: instances", full["R"], "->", cull["R"])
+    assert cull["R"] < 0.6 * full["R"]
+    # a Gaussian below 1/255 in opacity is listed nowhere; one that is listed keeps at least the tile of its mean if that is on screen
+    op = full["conic_opacity"][:, 3]
+    listed = np.zeros(op.size, bool)
+    listed[cull["point_list"]] = True
+    assert not listed[(op < 1.0 / 255.0)].any()

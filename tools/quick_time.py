@@ -9,14 +9,16 @@ from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-colour_only = len(sys.argv) > 3 and sys.argv[3] == "colour"  # depth / alpha / flow without upstream gradient (the training case)
+colour_only = len(sys.argv) > 3 and sys.argv[3] == "colour"
+tile_cull = not (len(sys.argv) > 4 and sys.argv[4] == "reflists")   # fdgs_forward_out.tile_cull, as the training step runs
+# depth / alpha / flow without upstream gradient (the training case)
 dev = torch.device("cuda:0")
 sc = scene_to_device(synth.make_scene(synth.CONFIGS[name], seed=0), dev)
 g = {k: v.to(dev) for k, v in synth.make_upstream_grads(sc["W"], sc["H"], seed=1, scale=1e-2).items()}
 e = torch.Tensor([])
 gg = lambda k: sc[k] if sc.get(k) is not None else e
 def fwd():
-    return _C.rasterize_gaussians(*native_args_fwd(sc))
+    return _C.rasterize_gaussians(*native_args_fwd(sc), tile_cull=tile_cull)
 def bwd(res):
     (R, color, flow, depth, T, radii, geom, binb, img, covs_com, om) = res
     return _C.rasterize_gaussians_backward(sc["bg"], sc["means3D"], om, radii, gg("colors_precomp"), gg("flow_2d"), sc["opacities"],

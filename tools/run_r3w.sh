@@ -1,16 +1,11 @@
-mkdir -p gpurun_out/r3B
-B="--cpu-samples 0 --dropin-steps 0 --host-cost-steps 0 --spatial-order-steps 0"
-for pad in 0 2048; do
-for sm in 0 1 2 4; do
-FDGS_BWD_LDS_PAD=$pad FDGS_BIN_SMALL=$sm python bench.py $B > gpurun_out/r3B/p${pad}_s${sm}.json 2>/dev/null
-done
-done
-FDGS_BWD_LDS_PAD=4096 FDGS_BIN_SMALL=4 python bench.py $B > gpurun_out/r3B/p4096_s4.json 2>/dev/null
-FDGS_BWD_LDS_PAD=4096 FDGS_BIN_SMALL=1 python bench.py $B > gpurun_out/r3B/p4096_s1.json 2>/dev/null
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+mkdir -p gpurun_out/r3E
+python bench.py > gpurun_out/r3E/bench_default.json 2>/dev/null; tail -c 300 gpurun_out/r3E/bench_default.json
+python bench.py --no-tile-cull --dropin-steps 0 > gpurun_out/r3E/bench_reflists.json 2>/dev/null
 python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/r3B/*.json')):
-    d=json.loads([l for l in open(f) if l.startswith('{')][-1])
-    st=d['stages']
-    print(f.split('/')[-1], d['value'], d['ms_per_step'], d['forward_ms'], {k:st[k]['ms'] for k in ('tile_count','tile_scatter','blend_bwd')})
+import json
+for n in ('bench_default','bench_reflists'):
+    d=json.loads([l for l in open('gpurun_out/r3E/%s.json'%n) if l.startswith('{')][-1])
+    print(n, d['value'], d['ms_per_step'], d['forward_ms'], d.get('raster_images_s'), d.get('spatial_order_images_s'), d['config'].get('num_rendered'), d['roofline']['frac'], d['roofline']['valu_issue_frac'], {k:v['ms'] for k,v in d['stages'].items()})
 PY
