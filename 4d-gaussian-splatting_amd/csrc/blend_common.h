@@ -2,7 +2,8 @@
 //
 // Work decomposition: one wave64 (= one 64-thread workgroup) owns one 8x8 pixel
 // block, four blocks per 16x16 tile.  The tile list itself (point_list / ranges) is
-// the reference's AABB list, bit-identical to the oracle; what changes is how a wave
+// the reference's AABB list, bit-identical to the oracle (with fdgs_forward_out.tile_cull: that list
+// without the instances that cannot reach alpha >= 1/255 in the tile, preprocess_fwd.hip); what changes is how a wave
 // consumes it: each lane fetches ONE list entry, tests whether that Gaussian can
 // reach alpha >= 1/255 anywhere inside the wave's pixel block (exact minimum of the
 // conic quadratic over the block rectangle, conservative slack), and the survivors
