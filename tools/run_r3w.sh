@@ -1,11 +1,17 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-mkdir -p gpurun_out/r3E
-python bench.py > gpurun_out/r3E/bench_default.json 2>/dev/null; tail -c 300 gpurun_out/r3E/bench_default.json
-python bench.py --no-tile-cull --dropin-steps 0 > gpurun_out/r3E/bench_reflists.json 2>/dev/null
+mkdir -p gpurun_out/r3F
+python -m pytest tests -m gpu -x -q -k "backward or parity or api or golden or tile_cull or analytic or densif or harness" 2>&1 | tail -3
+B="--cpu-samples 0 --dropin-steps 0 --host-cost-steps 0 --spatial-order-steps 0"
+for w in 0 512 1172 1536; do
+FDGS_PRE_BWD_WGS=$w python bench.py $B > gpurun_out/r3F/r_w$w.json 2>/dev/null
+FDGS_PRE_BWD_WGS=$w python bench.py $B --spatial-order > gpurun_out/r3F/m_w$w.json 2>/dev/null
+done
+FDGS_LIB=tools/ab/libfdgs_cull.so python bench.py $B > gpurun_out/r3F/r_old.json 2>/dev/null
+FDGS_LIB=tools/ab/libfdgs_cull.so python bench.py $B --spatial-order > gpurun_out/r3F/m_old.json 2>/dev/null
+python bench.py $B --workload C5 --steps 10 --warmup 3 > gpurun_out/r3F/c5_new.json 2>/dev/null
+FDGS_LIB=tools/ab/libfdgs_cull.so python bench.py $B --workload C5 --steps 10 --warmup 3 > gpurun_out/r3F/c5_old.json 2>/dev/null
 python - <<'PY'
-import json
-for n in ('bench_default','bench_reflists'):
-    d=json.loads([l for l in open('gpurun_out/r3E/%s.json'%n) if l.startswith('{')][-1])
-    print(n, d['value'], d['ms_per_step'], d['forward_ms'], d.get('raster_images_s'), d.get('spatial_order_images_s'), d['config'].get('num_rendered'), d['roofline']['frac'], d['roofline']['valu_issue_frac'], {k:v['ms'] for k,v in d['stages'].items()})
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r3F/*.json')):
+    d=json.loads([l for l in open(f) if l.startswith('{')][-1])
+    print(f.split('/')[-1], d['value'], d['ms_per_step'], {k:v['ms'] for k,v in d['stages'].items() if 'bwd' in k})
 PY
