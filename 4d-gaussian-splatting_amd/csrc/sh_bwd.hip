@@ -386,14 +386,6 @@ namespace fdgs
 		return per_cu * cus;
 	}
 
-	// FDGS_SH_BWD_WAVES=n (probe switch): waves per launch instead of the device's slots
-	static int sh_bwd_waves_override()
-	{
-		static int v = -1;
-		if (v < 0) { const char* e = getenv("FDGS_SH_BWD_WAVES"); v = e ? max(0, atoi(e)) : 0; }
-		return v;
-	}
-
 	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out, const char* geom, hipStream_t stream)
 	{
 		if (s.shs == nullptr || s.M <= 0) return hipSuccess;
@@ -418,7 +410,7 @@ namespace fdgs
 		if (slots == 0) slots = k ? resident_waves(sh_bwd_kernel<true>) : resident_waves(sh_bwd_kernel<false>);
 		// 1.5 waves per slot: ~1.5 chunks = ~55 live Gaussians per wave on C3, i.e. ONE evaluation batch for most waves and two
 		// rounds of them (C3, random / Morton order: 41 / 42 us; one wave per slot 43 / 50; spans of 128 as before 52 / 43)
-		const int grid = min(sh_bwd_waves_override() > 0 ? sh_bwd_waves_override() : slots + slots / 2, div_up(s.P, WAVE));
+		const int grid = min(slots + slots / 2, div_up(s.P, WAVE));
 		if (out.sh_stage) hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(grid), dim3(WAVE), 0, stream, a);
 		else hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(grid), dim3(WAVE), 0, stream, a);
 		return hipGetLastError();
