@@ -109,7 +109,7 @@ def parse_args():
                     help="A/B: the reference's tile lists (every tile of the 3-sigma square) instead of fdgs_forward_out.tile_cull "
                          "(a Gaussian listed only where it can reach alpha >= 1/255: same pixels and gradients)")
     ap.add_argument("--dense-sh-exchange", action="store_true",
-                    help="N > 1: always all-reduce the dense SH gradient (default: up to 16 views per step over all ranks exchange "
+                    help="N > 1: always all-reduce the dense SH gradient (default: up to 32 views per step over all ranks exchange "
                          "the views' 32-byte SH stages by all-gather instead, train_host.gather_view_stage_begin)")
     return ap.parse_args()
 
