@@ -25,8 +25,17 @@ namespace fdgs
 	constexpr int SR = 5;                // window radius (11 taps)
 	constexpr int SW = STX + 2 * SR;     // 42: tile + halo, columns
 	constexpr int SHH = STY + 2 * SR;    // 26: rows
-	constexpr int SSTR = 44;             // LDS row stride of the input tile, in (x,y) pairs (16-byte aligned rows for b128 reads)
-	constexpr int HSTR = 36;             // LDS row stride of the horizontally filtered moments
+	// LDS row strides (16-byte aligned rows for the b128 accesses), chosen for the banks.  In the horizontal pass 8 threads take a
+	// row and a wave 8 rows; a thread's b128 touches 4 of every 8 dwords of a pair-array row, so consecutive rows must be offset by
+	// 4 (mod 8) dwords or all 8 rows fall on the same half of the banks (measured with strides 44 / 36: 41 % of the backward's LDS
+	// cycles were bank conflicts): 46 and 38 pairs = 92 and 76 dwords.  Scalar arrays read / written 32 dwords per row: 48 (rows 0,
+	// 48, 32, 16 mod 64: every bank four times per b128, the minimum).  Effect: 86 -> 85 us for forward + backward: the conflicts were not what holds the
+	// kernels at 74 % / 52 % of their VALU issue bound.
+	constexpr int SSTR = 46;             // input tile, in (x,y) pairs
+	constexpr int SSTR1 = 48;            // input tile of the backward's scalar map
+	constexpr int HSTR = 38;             // horizontally filtered moments, pair arrays
+	constexpr int HSTR1F = 48;           // horizontally filtered scalar moment of the forward
+	constexpr int HSTR1B = 36;           // ... of the backward (48 would cost its sixth workgroup per CU)
 	constexpr int STHREADS = 256;
 	typedef float v2f __attribute__((ext_vector_type(2)));
 	typedef float v4f __attribute__((ext_vector_type(4)));
@@ -44,7 +53,7 @@ namespace fdgs
 		__shared__ __attribute__((aligned(16))) v2f s_in[SHH][SSTR];   // (x, y)
 		__shared__ __attribute__((aligned(16))) v2f h_m[SHH][HSTR];     // horizontally filtered (x, y)
 		__shared__ __attribute__((aligned(16))) v2f h_s[SHH][HSTR];     // (x^2, y^2)
-		__shared__ __attribute__((aligned(16))) float h_x[SHH][HSTR];   // x y
+		__shared__ __attribute__((aligned(16))) float h_x[SHH][HSTR1F];  // x y
 		__shared__ float red[2][STHREADS / WAVE];
 
 		const int c = blockIdx.z;
@@ -161,9 +170,9 @@ namespace fdgs
 		const float* __restrict__ upstream, float w_l1, float w_ssim, float* __restrict__ dL_dimg1)
 	{
 		__shared__ __attribute__((aligned(16))) v2f s_p[SHH][SSTR];    // (dm/dmu1, dm/dE11)
-		__shared__ __attribute__((aligned(16))) float s_q[SHH][SSTR];  // dm/dE12
+		__shared__ __attribute__((aligned(16))) float s_q[SHH][SSTR1]; // dm/dE12
 		__shared__ __attribute__((aligned(16))) v2f h_p[SHH][HSTR];
-		__shared__ __attribute__((aligned(16))) float h_q[SHH][HSTR];
+		__shared__ __attribute__((aligned(16))) float h_q[SHH][HSTR1B];
 
 		const int c = blockIdx.z;
 		const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
