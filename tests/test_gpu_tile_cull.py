@@ -44,6 +44,8 @@ CASES = {
     "dim3_sh2": lambda: synth.make_scene(SC("v", 8000, 256, 256, 2, 0, 0.03, 1.0, False, 3, False), seed=3, random_flow=True),
     "ragged_33x17": lambda: synth.make_scene(SC("v", 500, 33, 17, 3, 0, 0.05, 1.0, True, 4, True), seed=3),
     "adversarial": _adversarial,
+    # debug = the exact-size path of the forward (no run-ahead; stage by stage with synchronisation)
+    "dim4_debug": lambda: dict(synth.make_scene(SC("v", 8000, 250, 130, 1, 0, 0.03, 1.0, False, 4, True), seed=3, bg=(0.1, 0.2, 0.3)), debug=True),
 }
 
 
