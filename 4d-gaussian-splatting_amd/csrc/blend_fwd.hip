@@ -18,6 +18,9 @@ namespace fdgs
 {
 	typedef float v2f __attribute__((ext_vector_type(2)));
 
+	// FLOW = false: the scene has no flow_2d input (fdgs_scene.flows == NULL, the training default): every record's flow is zero, so
+	// is the flow image -- its two accumulators, their queue row and its LDS traffic are left out and zeros are stored.
+	template <bool FLOW>
 	__global__ void __launch_bounds__(WAVE) blend_fwd_kernel(
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
 		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
@@ -82,7 +85,8 @@ namespace fdgs
 				float* q4 = reinterpret_cast<float*>(&s_q[4][pr]) + h;
 				float* q5 = reinterpret_cast<float*>(&s_q[5][pr]) + h;
 				q0[0] = a.x; q0[2] = a.y; q1[0] = a.z; q1[2] = a.w; q2[0] = b.x; q2[2] = b.y;
-				q3[0] = b.z; q3[2] = b.w; q4[0] = c.x; q4[2] = c.y; q5[0] = c.z; q5[2] = c.w;
+				q3[0] = b.z; q3[2] = b.w; q4[0] = c.x; q4[2] = c.y;
+				if (FLOW) { q5[0] = c.z; q5[2] = c.w; }
 				(reinterpret_cast<uint32_t*>(&s_q[6][pr]))[h] = (uint32_t)pos + 1u;
 			}
 			if (lane == 0 && (cnt & 1))
@@ -90,7 +94,7 @@ namespace fdgs
 				// inert second half of the last pair: opacity 0 -> alpha 0 -> rejected
 				const int pr = cnt >> 1;
 #pragma unroll
-				for (int k = 0; k < 6; k++) { float* q = reinterpret_cast<float*>(&s_q[k][pr]) + 1; q[0] = 0.f; q[2] = 0.f; }
+				for (int k = 0; k < (FLOW ? 6 : 5); k++) { float* q = reinterpret_cast<float*>(&s_q[k][pr]) + 1; q[0] = 0.f; q[2] = 0.f; }
 				(reinterpret_cast<uint32_t*>(&s_q[6][pr]))[1] = 0u;
 			}
 			__syncthreads(); // single-wave workgroup: orders the LDS writes before the cross-lane reads
@@ -102,7 +106,9 @@ namespace fdgs
 			const int npairs = (cnt + 1) >> 1;
 			for (int i = 0; i < npairs; i++)
 			{
-				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i], Q5 = s_q[5][i];
+				const float4 Q0 = s_q[0][i], Q1 = s_q[1][i], Q2 = s_q[2][i], Q3 = s_q[3][i], Q4 = s_q[4][i];
+				float4 Q5 = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (FLOW) Q5 = s_q[5][i];
 				const uint2 pp = *reinterpret_cast<const uint2*>(&s_q[6][i]);
 				const v2f dx = v2f{ Q0.x, Q0.y } - pixfx, dy = v2f{ Q0.z, Q0.w } - pixfy;
 				const v2f cA = { Q1.x, Q1.y }, cB = { Q1.z, Q1.w }, cC = { Q2.x, Q2.y }, op = { Q2.z, Q2.w };
@@ -132,8 +138,11 @@ namespace fdgs
 				acc_g = __builtin_elementwise_fma(v2f{ Q3.z, Q3.w }, w, acc_g);
 				acc_b = __builtin_elementwise_fma(v2f{ Q4.x, Q4.y }, w, acc_b);
 				acc_d = __builtin_elementwise_fma(v2f{ Q4.z, Q4.w }, w, acc_d);
-				acc_fx = __builtin_elementwise_fma(v2f{ Q5.x, Q5.y }, w, acc_fx);
-				acc_fy = __builtin_elementwise_fma(v2f{ Q5.z, Q5.w }, w, acc_fy);
+				if (FLOW)
+				{
+					acc_fx = __builtin_elementwise_fma(v2f{ Q5.x, Q5.y }, w, acc_fx);
+					acc_fy = __builtin_elementwise_fma(v2f{ Q5.z, Q5.w }, w, acc_fy);
+				}
 				if (done == ~0ull) break;
 			}
 			__syncthreads(); // the queue is rewritten by the next chunk
@@ -148,8 +157,8 @@ namespace fdgs
 			out_color[0 * HW + pix_id] = (acc_r.x + acc_r.y) + T * bg[0];
 			out_color[1 * HW + pix_id] = (acc_g.x + acc_g.y) + T * bg[1];
 			out_color[2 * HW + pix_id] = (acc_b.x + acc_b.y) + T * bg[2];
-			out_flow[0 * HW + pix_id] = acc_fx.x + acc_fx.y;
-			out_flow[1 * HW + pix_id] = acc_fy.x + acc_fy.y;
+			out_flow[0 * HW + pix_id] = FLOW ? acc_fx.x + acc_fx.y : 0.0f;
+			out_flow[1 * HW + pix_id] = FLOW ? acc_fy.x + acc_fy.y : 0.0f;
 			out_depth[pix_id] = acc_d.x + acc_d.y;
 		}
 	}
@@ -161,10 +170,13 @@ namespace fdgs
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
 		const int ntiles = gx * gy;
 		if (s.P >= (1 << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets into the 48-byte records
-		hipLaunchKernelGGL(blend_fwd_kernel, dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream,
-		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records),
-		                   tile_order, s.W, s.H, gx, ntiles, s.bg,
-		                   out.out_color, out.out_flow, out.out_depth, out.out_T, final_T, n_contrib);
+#define LAUNCH_FWD(FLOW) hipLaunchKernelGGL(blend_fwd_kernel<FLOW>, dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream, \
+		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records), \
+		                   tile_order, s.W, s.H, gx, ntiles, s.bg, \
+		                   out.out_color, out.out_flow, out.out_depth, out.out_T, final_T, n_contrib)
+		if (s.flows != nullptr) LAUNCH_FWD(true);
+		else LAUNCH_FWD(false);
+#undef LAUNCH_FWD
 		return hipGetLastError();
 	}
 
