@@ -178,10 +178,70 @@ class ReferenceStyleModel:
     get_t = property(lambda s: s._t)
     get_scaling = property(lambda s: torch.exp(s._scaling))
     get_scaling_t = property(lambda s: torch.exp(s._scaling_t))
+    get_scaling_xyzt = property(lambda s: torch.exp(torch.cat([s._scaling, s._scaling_t], dim=1)))
     get_rotation = property(lambda s: F.normalize(s._rotation))
     get_rotation_r = property(lambda s: F.normalize(s._rotation_r))
     get_opacity = property(lambda s: torch.sigmoid(s._opacity))
     get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+    # ---- the Python-side covariance of ``pipe.compute_cov3D_python`` (gaussian_renderer/__init__.py:73-81) ----
+    # Restated from scene/gaussian_model.py:28-52, 230-251 and utils/general_utils.py:64-151 (device-agnostic; the reference
+    # hard-codes "cuda"); pinned against the reference's own functions by tests/golden/pycov_*.npz (make_golden_pycov.py).
+    def get_covariance(self, scaling_modifier=1):
+        """3D: Sigma = (S R)^T (S R), upper triangle [xx, xy, xz, yy, yz, zz] (gaussian_model.py:28-32, 244-245)."""
+        L = scaling_rotation_3d(scaling_modifier * self.get_scaling, self._rotation)
+        return upper_triangle(L.transpose(1, 2) @ L)
+
+    def get_current_covariance_and_mean_offset(self, scaling_modifier=1, timestamp=0.0):
+        """rot_4d: the 3D covariance conditioned on t = timestamp and the shift of the mean (gaussian_model.py:34-47, 247-251)."""
+        L = scaling_rotation_4d(scaling_modifier * self.get_scaling_xyzt, self._rotation, self._rotation_r)
+        sigma = L @ L.transpose(1, 2)
+        c12, ct = sigma[:, 0:3, 3:4], sigma[:, 3:4, 3:4]
+        cond = sigma[:, :3, :3] - c12 @ c12.transpose(1, 2) / ct
+        dt = timestamp - self.get_t
+        return upper_triangle(cond), c12.squeeze(-1) / ct.squeeze(-1) * dt
+
+    def get_cov_t(self, scaling_modifier=1):
+        """Temporal variance (gaussian_model.py:230-236): Sigma_tt with rot_4d, else the activated scaling_t itself."""
+        if self.rot_4d:
+            L = scaling_rotation_4d(scaling_modifier * self.get_scaling_xyzt, self._rotation, self._rotation_r)
+            return (L @ L.transpose(1, 2))[:, 3, 3].unsqueeze(1)
+        return self.get_scaling_t * scaling_modifier
+
+    def get_marginal_t(self, timestamp, scaling_modifier=1):
+        """exp(-(t - timestamp)^2 / (2 (sigma_t [+ prefilter_var]))) (gaussian_model.py:238-242)."""
+        sigma = self.get_cov_t(scaling_modifier)
+        if self.prefilter_var > 0.0:
+            sigma = sigma + self.prefilter_var
+        return torch.exp(-0.5 * (self.get_t - timestamp) ** 2 / sigma)
+
+
+def upper_triangle(sym: torch.Tensor) -> torch.Tensor:
+    """[n,3,3] symmetric -> [n,6] = xx, xy, xz, yy, yz, zz (utils/general_utils.py:64-77)."""
+    return torch.stack([sym[:, 0, 0], sym[:, 0, 1], sym[:, 0, 2], sym[:, 1, 1], sym[:, 1, 2], sym[:, 2, 2]], dim=1)
+
+
+def scaling_rotation_3d(s: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    """diag(s) @ R(q / |q|), q = (w, x, y, z) (utils/general_utils.py:79-111)."""
+    q = q / torch.sqrt((q * q).sum(dim=1, keepdim=True))
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+    return s.unsqueeze(2) * R
+
+
+def scaling_rotation_4d(s: torch.Tensor, ql: torch.Tensor, qr: torch.Tensor) -> torch.Tensor:
+    """R4(ql, qr) @ diag(s): the product of the left- and right-isoclinic rotations of the two unit quaternions, rows and
+    columns reversed (utils/general_utils.py:113-151)."""
+    ql = ql / torch.norm(ql, dim=-1, keepdim=True)
+    qr = qr / torch.norm(qr, dim=-1, keepdim=True)
+    a, b, c, d = ql.unbind(-1)
+    p, q, r, t = qr.unbind(-1)
+    Ml = torch.stack([a, -b, -c, -d, b, a, -d, c, c, d, a, -b, d, -c, b, a], dim=1).view(-1, 4, 4)
+    Mr = torch.stack([p, q, r, t, -q, p, -t, r, -r, t, p, -q, -t, -r, q, p], dim=1).view(-1, 4, 4)
+    A = (Ml @ Mr).flip(1, 2)
+    return A * s.unsqueeze(1)
 
 
 class FlatAdam:
@@ -492,6 +552,22 @@ class SyntheticCamera:
         self.full_proj_transform = scene["full_proj_transform"].to(device)
         self.camera_center = scene["camera_center"].to(device)
         self.timestamp = scene["timestamp"] if timestamp is None else timestamp
+        # pinhole intrinsics of the synthetic camera (scene/cameras.py:33-36: cx, cy, fl_x, fl_y), read by get_rays
+        self.fl_x = self.image_width / (2.0 * math.tan(0.5 * self.FoVx))
+        self.fl_y = self.image_height / (2.0 * math.tan(0.5 * self.FoVy))
+        self.cx, self.cy = 0.5 * self.image_width, 0.5 * self.image_height
+
+    def get_rays(self):
+        """(origin [1,1,3], unit directions [H,W,3]) of the pixel centres in world space (scene/cameras.py:75-82; used by the
+        environment-map branch of render(), gaussian_renderer/__init__.py:165-176)."""
+        dev = self.world_view_transform.device
+        ys, xs = torch.meshgrid(torch.arange(self.image_height, dtype=torch.float32, device=dev) + 0.5,
+                                torch.arange(self.image_width, dtype=torch.float32, device=dev) + 0.5, indexing="ij")
+        one = torch.ones_like(xs)
+        pts_view = torch.stack([(xs - self.cx) / self.fl_x, (ys - self.cy) / self.fl_y, one, one], dim=-1)
+        c2w = torch.linalg.inv(self.world_view_transform.transpose(0, 1))
+        d = (pts_view @ c2w.T)[..., :3] - self.camera_center[None, None, :]
+        return self.camera_center[None, None], d / torch.norm(d, dim=-1, keepdim=True)
 
 
 class PipelineFlags:

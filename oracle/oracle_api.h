@@ -130,6 +130,13 @@ int oracle_block_any_pixel_passes(int n, const float* tuples, uint8_t* out);
 const char* oracle_kind(void);
 /* Number of OS threads the oracle uses (OpenMP). */
 int oracle_threads(void);
+/* Accumulation order / precision of the per-Gaussian sums of the blend backward (process-wide, default 0):
+ *   0  the reference: fp32 atomicAdd per (pixel, contributor), tiles / threads of a block in index order;
+ *   1  the same fp32 atomics with the tiles and the threads of a block visited in REVERSE order -- another legal execution
+ *      order of the same CUDA kernel: 0 vs 1 is the reference's own accumulation-order noise (both oracles);
+ *   2  (port oracle only; the verbatim build answers -1) the same terms accumulated in double, rounded to fp32 once.
+ * Returns 0, or -1 when the mode is not supported by this oracle. */
+int oracle_set_accumulation(int mode);
 
 #ifdef __cplusplus
 }

@@ -254,6 +254,16 @@ def mark_visible(means3D, viewmatrix, projmatrix, kind="port"):
     return out.astype(bool)
 
 
+def set_accumulation(mode, kind="port"):
+    """oracle_set_accumulation (oracle_api.h): 0 = the reference's fp32 atomics in index order, 1 = the same atomics with tiles
+    and threads in reverse order (another legal execution order of the same kernel), 2 = double accumulation (port only)."""
+    lib = _load(kind)
+    lib.oracle_set_accumulation.argtypes = [C.c_int]
+    lib.oracle_set_accumulation.restype = C.c_int
+    if lib.oracle_set_accumulation(int(mode)) != 0:
+        raise ValueError("oracle %r does not support accumulation mode %r" % (kind, mode))
+
+
 def threads(kind="port"):
     return int(_load(kind).oracle_threads())
 

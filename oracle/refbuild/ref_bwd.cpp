@@ -5,14 +5,25 @@
 #include "ref_internal.h"
 #include "ref_emu.h"
 
+int g_ref_acc_mode = 0;
+extern "C" int oracle_set_accumulation(int mode)
+{
+	if (mode != 0 && mode != 1) return -1;   // the double-accumulation mode is the port oracle's
+	g_ref_acc_mode = mode;
+	return 0;
+}
+
 // Mirrors the launch at backward.cu:1254.
 void ref_render_bwd_all(oracle_io* io, dim3 grid)
 {
 	const float* color_ptr = io->colors_precomp ? io->colors_precomp : io->rgb; // rasterizer_impl.cu:433
 	const int ntiles = (int)(grid.x * grid.y);
+	const bool reverse = g_ref_acc_mode == 1;   // oracle_set_accumulation(1): tiles and threads in descending order
 #pragma omp parallel for schedule(dynamic, 4)
-	for (int t = 0; t < ntiles; t++)
+	for (int ti = 0; ti < ntiles; ti++)
 	{
+		const int t = reverse ? ntiles - 1 - ti : ti;
+		refemu::runner().reverse = reverse;
 		std::function<void()> body = [&]() {
 			renderCUDA<NUM_CHANNELS>(
 				(const uint2*)io->ranges, io->point_list, io->W, io->H, io->bg,
@@ -23,6 +34,7 @@ void ref_render_bwd_all(oracle_io* io, dim3 grid)
 				io->dL_dcolor, io->dL_dflows);
 		};
 		refemu::runner().run(dim3(t % grid.x, t / grid.x, 0), dim3(BLOCK_X, BLOCK_Y, 1), body);
+		refemu::runner().reverse = false;   // the forward / kNN kernels always run in ascending order
 	}
 }
 

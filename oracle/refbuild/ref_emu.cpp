@@ -43,8 +43,9 @@ namespace refemu
 		while (alive > 0)
 		{
 			alive = 0;
-			for (int t = 0; t < n; t++)
+			for (int ti = 0; ti < n; ti++)
 			{
+				const int t = reverse ? n - 1 - ti : ti;   // any order is a legal schedule: fibers only meet at barriers
 				if (done[t]) continue;
 				cur = t;
 				g_ctx = ids[t];

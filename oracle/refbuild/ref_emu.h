@@ -28,6 +28,7 @@ namespace refemu
 		int phase = 0;
 		int acc[2] = { 0, 0 };
 		const std::function<void()>* body = nullptr;
+		bool reverse = false;   // fibers resumed in descending thread order between barriers (oracle_set_accumulation(1))
 
 		void ensure(int n)
 		{

@@ -2,7 +2,7 @@
 """Generates the golden fixtures under tests/golden/ with the reference's OWN kernel source compiled for the
 CPU (oracle/_ref/liboracle_ref.so, built by oracle/refbuild/build_ref.py from /root/reference).
 
-Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py [fixture names]
 Each fixture is a compressed .npz holding the seeded inputs (regenerable from fdgs.synth with the stored
 config / seed, kept anyway so the file is self-contained) and every forward intermediate and gradient the
 reference produces: radii, tiles_touched, depths, means2D, conic_opacity, rgb, cov3D, out_means3D, clamped,
@@ -29,6 +29,15 @@ FIXTURES = {
     "rot4d_sh0": (SC("g", 900, 96, 96, 0, 0, 0.04, 1.0, True, 4, True), 12, dict()),
     "dim3_sh2": (SC("g", 700, 100, 60, 2, 0, 0.04, 1.0, False, 3, False), 13, dict(random_flow=True)),
     "dim4_norot_sh1": (SC("g", 700, 90, 70, 1, 0, 0.04, 1.0, False, 4, True), 14, dict(bg=(1.0, 1.0, 1.0))),
+    # the two flags no other fixture sets: scale_modifier != 1 (forward.cu:418-434, backward.cu:911-916) and prefilter_var > 0
+    # (forward.cu:333, 434, backward.cu:746), on the rot_4d path and on the 3D-covariance + temporal-marginal path
+    "rot4d_sh1t1_mod07_pf02": (SC("g", 500, 88, 72, 1, 1, 0.05, 4.0, True, 4, False), 15, dict(random_flow=True, bg=(0.1, 0.0, 0.3))),
+    "dim4_norot_sh2_mod16_pf005": (SC("g", 500, 96, 64, 2, 0, 0.03, 1.0, False, 4, True), 16, dict()),
+}
+# scene-dict overrides applied after make_scene (the flags travel in the fixture as sc_scale_modifier / sc_prefilter_var)
+OVERRIDES = {
+    "rot4d_sh1t1_mod07_pf02": dict(scale_modifier=0.7, prefilter_var=0.2),
+    "dim4_norot_sh2_mod16_pf005": dict(scale_modifier=1.6, prefilter_var=0.05),
 }
 
 INPUT_KEYS = ("means3D", "ts", "scales", "scales_t", "rotations", "rotations_r", "opacities", "shs", "flow_2d", "bg",
@@ -39,13 +48,18 @@ SCALAR_KEYS = ("W", "H", "sh_degree", "sh_degree_t", "timestamp", "time_duration
 
 def scene_for(name):
     cfg, seed, kw = FIXTURES[name]
-    return synth.make_scene(cfg, seed=seed, **kw)
+    sc = synth.make_scene(cfg, seed=seed, **kw)
+    sc.update(OVERRIDES.get(name, {}))
+    return sc
 
 
 def main():
     if pyoracle.build_ref() is None:
         raise SystemExit("needs /root/reference to build oracle/_ref/liboracle_ref.so")
+    only = sys.argv[1:]   # fixture names to (re)generate; default: all (gradients differ in the last bits from run to run: atomics)
     for name in FIXTURES:
+        if only and name not in only:
+            continue
         sc = scene_for(name)
         g = synth.make_upstream_grads(sc["W"], sc["H"], seed=1, scale=1e-2)
         o = pyoracle.Oracle(sc, kind="reference")

@@ -48,6 +48,37 @@ def test_forward_backward_vs_oracle(name, gpu_device):
     print(name, {k: "%.2e/%.1e" % v for k, v in repg.items()})
 
 
+# scale_modifier != 1 (forward.cu:418-434 scales every axis incl. the temporal one, backward.cu:911-916) and prefilter_var > 0
+# (the temporal marginal's variance floor: forward.cu:333 / 434, backward.cu:746) -- the two settings no other scene sets
+# (gaussian_renderer/__init__.py:43 scaling_modifier, arguments/__init__.py:62 prefilter_var); with the reference's lists and
+# with tile_cull (the reachable rectangle depends on the opacity the marginal scales).
+@pytest.mark.parametrize("tile_cull", [False, True])
+@pytest.mark.parametrize("mod,pv", [(0.5, 0.01), (2.0, 0.3), (0.5, 0.3), (2.0, 0.01)])
+@pytest.mark.parametrize("name", ["rot4d_sh3_t1", "dim4_norot_sh1", "rot4d_sh2_4d"])
+def test_scale_modifier_and_prefilter_var_vs_oracle(name, mod, pv, tile_cull, gpu_device):
+    scene = _scene(name)
+    scene["scale_modifier"], scene["prefilter_var"] = mod, pv
+    grads = synth.make_upstream_grads(scene["W"], scene["H"], seed=1, scale=GRAD_SCALE)
+    hip, hipg = run_hip(scene, gpu_device, grads, tile_cull=tile_cull)
+    ref, refg = run_oracle(scene, grads, kind="port")
+    base, _ = run_oracle(_scene(name), None, kind="port")
+    assert ref["R"] != base["R"], "the flags changed nothing: the case does not test them"
+    rep = check_forward(hip, ref, "%s mod %g pv %g" % (name, mod, pv), tile_cull=tile_cull, WH=(scene["W"], scene["H"]), max_border=2e-3)
+    repg = check_backward(hipg, refg, "%s mod %g pv %g" % (name, mod, pv))
+    print(name, mod, pv, "R", ref["R"], "(default flags: %d)" % base["R"], {k: "%.2e/%.1e" % v for k, v in repg.items()})
+
+
+def test_scale_modifier_3d_vs_oracle(gpu_device):
+    """gaussian_dim == 3 has no temporal marginal: scale_modifier alone (computeCov3D, forward.cu:242-276)."""
+    scene = _scene("dim3_sh2")
+    scene["scale_modifier"] = 1.7
+    grads = synth.make_upstream_grads(scene["W"], scene["H"], seed=1, scale=GRAD_SCALE)
+    hip, hipg = run_hip(scene, gpu_device, grads)
+    ref, refg = run_oracle(scene, grads, kind="port")
+    check_forward(hip, ref, "dim3 mod 1.7", max_border=2e-3)
+    check_backward(hipg, refg, "dim3 mod 1.7")
+
+
 def test_precomputed_cov_and_colors(gpu_device):
     """cov3D_precomp + colors_precomp branch (forward.cu:411-414, 476): feed the oracle's own cov3D / rgb back in."""
     base = synth.make_scene(SC("v", 6000, 200, 160, 1, 0, 0.03, 1.0, True, 4, True), seed=5)
@@ -125,7 +156,7 @@ def test_depth_only_backward_vs_oracle(gpu_device):
 # The configuration the metric is quoted on, through the path bench.py times
 # ----------------------------------------------------------------------------------------------------------------
 
-def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
+def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, scale_modifier=1.0, prefilter_var=-1.0):
     """The calls fdgs/pipeline.py::StepPipeline makes for one optimizer step -- raw parameters (activations fused into
     the kernels, fdgs_scene.raw_params = 1), fused L1 + SSIM gradient as the only upstream gradient (colour-only blend
     backward), parameter gradients accumulated over the views into the flat bucket, persistent always-zero blend
@@ -133,9 +164,10 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
     derive themselves (fdgs_debug_activations: same device functions, bit-identical), and its gradients are pulled
     back to the raw parameters in float64, so the 1e-4 bar applies to this mode unchanged.
     Bar: radii / tiles_touched / depth bits / point_list / sorted tile ids / ranges bit-exact, n_contrib equal and
-    pixels <= 1e-4 abs off the flagged cliff pixels, every gradient <= 1e-4 * max(1, max|ref|).
-    ``tile_cull`` (what StepPipeline runs with): the lists are the reference's with the instances taken out that cannot reach
-    alpha >= 1/255 in their tile -- checked as such (util.check_culled_lists) instead of bit for bit."""
+    pixels <= 1e-4 abs off the flagged cliff pixels, every gradient <= 1e-4 * max(1, max|ref|) -- except that the four
+    covariance-chain tensors are held to max(that, COV_CHAIN_K x the reference's OWN accumulation-order spread), measured here
+    (see below).  ``tile_cull`` (what StepPipeline runs with): the lists are the reference's with the instances taken out that
+    cannot reach alpha >= 1/255 in their tile -- checked as such (util.check_culled_lists) instead of bit for bit."""
     from fdgs import _capi, train_host
     from fdgs.fused import raw_backward, raw_forward, raw_settings
     from fdgs.loss import l1_ssim_grad
@@ -144,6 +176,7 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
     scene = synth.make_scene(cfg, seed=0)
     P, W, H = int(scene["means3D"].shape[0]), scene["W"], scene["H"]
     model = train_host.GaussianParams(scene, dev)
+    model.prefilter_var = prefilter_var
     pipe = train_host.PipelineFlags()
     bg = scene["bg"].to(dev)
     dur = scene["time_duration"]
@@ -178,15 +211,19 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
             out[name] = (g - q * (q * g).sum(1, keepdims=True)) * inv
         return out
 
-    total = None
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
+             "dL_dscale", "dL_dscale_t", "dL_drot", "dL_drot_r")
+    zeros13 = (torch.zeros(1, H, W), torch.zeros(1, H, W), torch.zeros(2, H, W))
+    total = total_rev = total_f64 = None
     for b, cam in enumerate(cams):
-        rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(cam, model, pipe, bg)
+        rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(cam, model, pipe, bg, scale_modifier)
         res = raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, tile_cull=tile_cull)
         (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = res
         hip = collect_forward(res, P, W, H)
         g_color, _handle = l1_ssim_grad(color, gts[b], 0.2, up)
         osc = dict(scene)
-        osc.update(opacities=a_op, scales=a_sc, scales_t=a_sct, rotations=a_rot, rotations_r=a_rotr, timestamp=cam.timestamp)
+        osc.update(opacities=a_op, scales=a_sc, scales_t=a_sct, rotations=a_rot, rotations_r=a_rotr, timestamp=cam.timestamp,
+                   scale_modifier=scale_modifier, prefilter_var=prefilter_var)
         o = pyoracle.Oracle(osc, kind="port")
         ref = dict(o.forward())
         ref["R"] = o.R
@@ -197,29 +234,42 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
         cliff = torch.from_numpy(ref["border"].astype(bool)).to(dev)
         g_unmasked = g_color
         g_color = g_color * (~cliff).to(g_color.dtype)
-        if b == 0:
-            # The UNMASKED error, tracked and bounded: the same backward with the cliff pixels' upstream gradient left in, per-view
-            # outputs only (no sink: nothing is accumulated).  What it adds to the masked comparison is the effect of alpha >= 1/255 / T >= 1e-4
-            # decisions that fell the other way on the 5e-4 of the pixels that sit on a cliff -- bounded by 10 x the bar.
-            gu = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
-                              geom, R, binb, img, g_unmasked, None, None, None, None, False, grad_accum=gacc)
-            torch.cuda.synchronize()
-            refu = dict(o.backward(g_unmasked.cpu(), torch.zeros(1, H, W), torch.zeros(1, H, W), torch.zeros(2, H, W)))
-            unm = {}
-            for n, t in zip(("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D"), gu):
-                if n in ("dL_dmean2D", "dL_dcolor", "dL_dcov3D"):
-                    want = refu[n]
-                    sc = max(1.0, float(np.abs(want).max()))
-                    e = float(np.abs(t.cpu().numpy().reshape(want.shape) - want).max())
-                    unm[n] = "%.2e/%.1e = %.2e of scale" % (e, sc, e / sc)
-                    assert e <= 1e-3 * sc, "%s view %d UNMASKED %s: %g > %g" % (label, b, n, e, 1e-3 * sc)
-            print("%s view %d UNMASKED per-view gradients (cliff pixels' upstream gradient kept; bound 1e-3 of scale):" % (label, b), unm)
+        # The UNMASKED error, tracked and bounded for EVERY view and ALL twelve gradient tensors: the same backward with the cliff
+        # pixels' upstream gradient left in (no sink: nothing is accumulated, the activated-parameter gradients come back as the
+        # binding's tuple -- raw-parameter chain rule applied to the oracle's side).  What it adds to the masked comparison is the
+        # effect of alpha >= 1/255 / T >= 1e-4 decisions that fell the other way on the ~5e-4 of the pixels that sit on a cliff:
+        # bounded by 10 x the bar.
+        gu = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
+                          geom, R, binb, img, g_unmasked, None, None, None, None, False, grad_accum=gacc)
+        torch.cuda.synchronize()
+        refu = dict(o.backward(g_unmasked.cpu(), *zeros13))
+        ru = to_raw(refu)
+        want_u = {"dL_dmean2D": refu["dL_dmean2D"], "dL_dcolor": refu["dL_dcolor"], "dL_dcov3D": refu["dL_dcov3D"], "dL_dflows": refu["dL_dflows"],
+                  "dL_dopacity": ru["_opacity"], "dL_dmean3D": ru["_xyz"], "dL_dsh": ru["_features"], "dL_dts": ru["_t"], "dL_dscale": ru["_scaling"],
+                  "dL_dscale_t": ru["_scaling_t"], "dL_drot": ru["_rotation"], "dL_drot_r": ru["_rotation_r"]}
+        unm = {}
+        for n, t in zip(names, gu):
+            want = want_u[n]
+            sc = max(1.0, float(np.abs(want).max()))
+            e = float(np.abs(t.cpu().numpy().reshape(want.shape) - want).max())
+            unm[n] = "%.1e/%.1e" % (e, sc)
+            assert e <= 1e-3 * sc, "%s view %d UNMASKED %s: %g > %g" % (label, b, n, e, 1e-3 * sc)
+        print("%s view %d UNMASKED gradients, all 12 tensors (cliff pixels' upstream gradient kept; max abs err / max|ref|; bound 1e-3 of scale):" % (label, b), unm)
+        del gu
         grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
                              geom, R, binb, img, g_color, None, None, None, sink, b > 0, grad_accum=gacc)
         torch.cuda.synchronize()
         assert float(gacc.abs().max()) == 0.0, "the persistent blend accumulator was not left all zero"
         gc = g_color.cpu()
-        refg = dict(o.backward(gc, torch.zeros(1, H, W), torch.zeros(1, H, W), torch.zeros(2, H, W)))
+        refg = dict(o.backward(gc, *zeros13))
+        # The reference against ITSELF: the same backward with (1) the blend backward's fp32 atomics issued in another legal order
+        # (tiles and threads descending, oracle_set_accumulation(1)) and (2) the per-Gaussian sums accumulated in double (mode 2).
+        # (0 vs 1) is the accumulation-order noise the reference carries on any GPU -- CUDA fixes no order for atomicAdd.
+        pyoracle.set_accumulation(1)
+        refg_rev = dict(o.backward(gc, *zeros13))
+        pyoracle.set_accumulation(2)
+        refg_f64 = dict(o.backward(gc, *zeros13))
+        pyoracle.set_accumulation(0)
         o.close()
         rep = check_forward(hip, ref, "%s view %d" % (label, b), max_border=max_border, tile_cull=tile_cull, WH=(W, H))
         if tile_cull:
@@ -227,22 +277,24 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
         print("%s view %d: R %d, cliff pixel fraction %.2e (upstream gradient zeroed there), max abs pixel err colour %.2e depth %.2e T %.2e" % (
             label, b, ref["R"], rep["border_frac"], rep["out_color"], rep["out_depth"], rep["out_T"]))
         # per-view outputs of the backward (always overwritten): viewspace gradient, colour, covariance
-        names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
-                 "dL_dscale", "dL_dscale_t", "dL_drot", "dL_drot_r")
         per_view = {n: t.cpu().numpy() for n, t in zip(names, grads) if n in ("dL_dmean2D", "dL_dcolor", "dL_dcov3D", "dL_dflows")}
         repg = check_backward(per_view, {k: refg[k] for k in per_view}, "%s view %d" % (label, b))
         print("%s view %d per-view gradients (max abs err / max|ref|):" % (label, b), {k: "%.2e/%.1e" % v for k, v in repg.items()})
-        r = to_raw(refg)
+        r, rr, r64 = to_raw(refg), to_raw(refg_rev), to_raw(refg_f64)
         total = r if total is None else {k: total[k] + r[k] for k in r}
+        total_rev = rr if total_rev is None else {k: total_rev[k] + rr[k] for k in rr}
+        total_f64 = r64 if total_f64 is None else {k: total_f64[k] + r64[k] for k in r64}
 
     got = {n: model.params[n].grad.detach().cpu().numpy() for n in model.NAMES}
-    line = {}
+    line, just = {}, {}
     # Gradients of the covariance parameters are cancelling sums of products of dL/dcov3D (O(1e3) here) with the
-    # scale / rotation matrices: an fp32 rounding difference of 1e-6 relative in dL/dcov3D -- the blend backward sums
-    # thousands of pixel terms per Gaussian with atomics, in a different order from the oracle -- is an absolute error
-    # of some 1e-3 in them whatever the implementation (the downstream kernel mirrors the oracle's arithmetic
-    # operation by operation).  For these four tensors the bar is therefore applied to all but 1e-3 of the elements,
-    # with the stragglers bounded by 1e-2 of the tensor scale; their input, dL/dcov3D, is held to the hard bar above.
+    # scale / rotation matrices: the chain amplifies a 1e-6 relative rounding difference in the blend backward's per-Gaussian
+    # sums -- thousands of fp32 atomics per Gaussian, in whatever order the hardware issues them -- by two to three orders of
+    # magnitude, in ANY implementation incl. the reference itself.  So for these four tensors the bar is
+    #     |hip - ref| <= max(1e-4 * scale, COV_CHAIN_K * max|ref - ref'|),
+    # ref' = the reference's own arithmetic with its atomics in another legal order (measured above, same inputs, same views):
+    # the HIP kernels may differ from the reference by no more than COV_CHAIN_K times what the reference differs from itself.
+    # Also printed: both against the double-accumulated sums (whose accumulation error is it?).
     cov_chain = ("_scaling", "_scaling_t", "_rotation", "_rotation_r")
     for n in model.NAMES:
         want = total[n].reshape(got[n].shape)
@@ -251,19 +303,42 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True):
         d = np.abs(got[n] - want)
         err = float(d.max())
         beyond = int((d > 1e-4 * scale).sum())
+        spread_d = np.abs(total_rev[n].reshape(got[n].shape) - want)
+        spread = float(spread_d.max())
         line[n] = "%.2e/%.1e" % (err, scale) + (" (%d of %d beyond 1e-4)" % (beyond, d.size) if beyond else "")
-        ok = err <= 1e-4 * scale or (n in cov_chain and beyond <= 1e-3 * d.size and err <= 1e-2 * scale)
-        if not ok:
+        f64 = total_f64[n].reshape(got[n].shape)
+        just[n] = "hip-ref %.2e | ref-ref' %.2e (%d beyond 1e-4) | hip-f64 %.2e | ref-f64 %.2e" % (
+            err, spread, int((spread_d > 1e-4 * scale).sum()), float(np.abs(got[n] - f64).max()), float(np.abs(want - f64).max()))
+        bound = 1e-4 * scale
+        if n in cov_chain:
+            bound = max(bound, COV_CHAIN_K * spread)
+        if not err <= bound:
             i = np.unravel_index(int(np.argmax(d)), d.shape)
-            raise AssertionError("%s: accumulated gradient of %s: max abs err %g > %g (max|ref| %g) at %s: got %r want %r; "
-                                 "%d elements beyond the bound" % (label, n, err, 1e-4 * scale, scale, i, got[n][i], want[i], beyond))
+            raise AssertionError("%s: accumulated gradient of %s: max abs err %g > %g (max|ref| %g; the reference's own order-to-order spread: %g) "
+                                 "at %s: got %r want %r; %d elements beyond 1e-4 of scale" % (label, n, err, bound, scale, spread, i, got[n][i], want[i], beyond))
     print("%s accumulated raw-parameter gradients over %d views (max abs err / max|ref|):" % (label, n_views), line)
+    print("%s covariance-chain justification (max abs over the tensor; ref' = reference with its atomics in reverse order, f64 = double-accumulated sums):" % label,
+          {n: just[n] for n in cov_chain})
+    return {n: just[n] for n in model.NAMES}
+
+
+# The four covariance-chain tensors (see _timed_path_vs_oracle): HIP may differ from the reference by at most this many times
+# the reference's own accumulation-order spread on the same inputs (beyond the plain 1e-4 bar).
+COV_CHAIN_K = 2.0
 
 
 @pytest.mark.parametrize("tile_cull", [False, True])
 def test_timed_path_small_vs_oracle(tile_cull, gpu_device):
     """The timed path (see _timed_path_vs_oracle) on a small scene, with the reference's lists and with tile_cull."""
     _timed_path_vs_oracle(SC("v", 30000, 400, 304, 3, 2, 0.015, 10.0, True, 4, False), gpu_device, 2, "timed-small", 1e-3, tile_cull=tile_cull)
+
+
+@pytest.mark.parametrize("mod,pv", [(0.5, 0.3), (2.0, 0.01)])
+def test_timed_path_small_with_flags_vs_oracle(mod, pv, gpu_device):
+    """The timed path (raw_params = 1, tile_cull = 1, colour-only backward, accumulation) with scale_modifier != 1 and
+    prefilter_var > 0 (forward.cu:333, 418-434; backward.cu:746, 911-916): the activations' chain rule meets the modifier."""
+    _timed_path_vs_oracle(SC("v", 12000, 320, 240, 3, 2, 0.015, 10.0, True, 4, False), gpu_device, 2, "timed-flags", 2e-3, tile_cull=True,
+                          scale_modifier=mod, prefilter_var=pv)
 
 
 @pytest.mark.parametrize("tile_cull", [True, False])
@@ -278,8 +353,8 @@ def test_c5_full_size_forward_backward_vs_oracle(gpu_device):
     """BASELINE configs[4] (2 M Gaussians, 2704x2028, R = 15.9 M): forward AND backward at full size against the port oracle
     (reference backward.cu:926-1137 + :486-923), both blend-backward variants: all four upstream gradients (AUX) and
     colour only.  As on C3 the upstream gradients are zeroed on the oracle-flagged cliff pixels on both sides; the bar is
-    1e-4 * max(1, max|ref|) per tensor, except that for the four covariance-chain tensors up to 1e-3 of the elements may
-    exceed it (bounded by 1e-2 of the scale; see _timed_path_vs_oracle)."""
+    1e-4 * max(1, max|ref|) per tensor; the four covariance-chain tensors: max(that, COV_CHAIN_K x the reference's own
+    accumulation-order spread on the same inputs) (see _timed_path_vs_oracle)."""
     scene = synth.make_scene(synth.CONFIGS["C5"], seed=0)
     W, H = scene["W"], scene["H"]
     o = pyoracle.Oracle(scene, kind="port")
@@ -299,7 +374,10 @@ def test_c5_full_size_forward_backward_vs_oracle(gpu_device):
         if variant == "aux":
             rep = check_forward(hip, ref, "C5", max_border=5e-4)
             print("C5 R", ref["R"], rep)
-        refg = dict(o.backward(ora_in["grad_color"], ora_in["grad_depth"], ora_in["grad_alpha"], ora_in["grad_flow"]))
+        refg = {k: v.copy() for k, v in o.backward(ora_in["grad_color"], ora_in["grad_depth"], ora_in["grad_alpha"], ora_in["grad_flow"]).items()}
+        pyoracle.set_accumulation(1)   # the reference's atomics in another legal order: its own spread
+        refg_rev = {k: v.copy() for k, v in o.backward(ora_in["grad_color"], ora_in["grad_depth"], ora_in["grad_alpha"], ora_in["grad_flow"]).items()}
+        pyoracle.set_accumulation(0)
         line = {}
         for k, want in refg.items():
             if k == "dL_dconic":
@@ -309,10 +387,12 @@ def test_c5_full_size_forward_backward_vs_oracle(gpu_device):
             scale = max(1.0, float(np.abs(want).max()) if want.size else 1.0)
             d = np.abs(got - want)
             err = float(d.max()) if d.size else 0.0
+            spread = float(np.abs(refg_rev[k] - want).max()) if want.size else 0.0
             beyond = int((d > 1e-4 * scale).sum())
-            line[k] = "%.2e/%.1e" % (err, scale) + (" (%d of %d beyond 1e-4)" % (beyond, d.size) if beyond else "")
-            ok = err <= 1e-4 * scale or (k in cov_chain and beyond <= 1e-3 * d.size and err <= 1e-2 * scale)
-            assert ok, "C5 %s: %s max abs err %g > %g (max|ref| %g), %d elements beyond" % (variant, k, err, 1e-4 * scale, scale, beyond)
+            line[k] = "%.2e/%.1e" % (err, scale) + (" (%d of %d beyond 1e-4; ref-ref' %.2e)" % (beyond, d.size, spread) if beyond else "")
+            bound = max(1e-4 * scale, COV_CHAIN_K * spread) if k in cov_chain else 1e-4 * scale
+            assert err <= bound, "C5 %s: %s max abs err %g > %g (max|ref| %g, reference's own spread %g), %d elements beyond 1e-4" % (
+                variant, k, err, bound, scale, spread, beyond)
         print("C5 %s gradients (max abs err / max|ref|):" % variant, line)
     o.close()
 

@@ -29,13 +29,30 @@ CASES = {
     "dim3_sh3": (SC("p", 2000, 128, 128, 3, 0, 0.03, 1.0, False, 3, False), dict(random_flow=True)),
     "dim4_norot_sh0": (SC("p", 2000, 130, 70, 0, 0, 0.03, 1.0, False, 4, True), dict(bg=(1.0, 0.5, 0.0))),
 }
+# scale_modifier != 1 (forward.cu:418-434, backward.cu:911-916) and prefilter_var > 0 (forward.cu:333, 434, backward.cu:746)
+FLAGS = {
+    "rot4d_sh3t2": [(0.5, 0.3), (2.0, 0.01)],
+    "dim4_norot_sh0": [(0.5, 0.01), (2.0, 0.3)],
+    "dim3_sh3": [(1.7, -1.0)],
+}
+
+
+def _flag_cases():
+    return [(n, m, p) for n, fl in FLAGS.items() for m, p in fl]
+
+
+@pytest.mark.parametrize("name,mod,pv", _flag_cases())
+def test_port_equals_verbatim_reference_with_flags(name, mod, pv):
+    """The two settings no default scene exercises, port restatement against the reference's own source."""
+    test_port_equals_verbatim_reference(name, 23, scale_modifier=mod, prefilter_var=pv)
 
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("seed", [21, 22])
-def test_port_equals_verbatim_reference(name, seed):
+def test_port_equals_verbatim_reference(name, seed, scale_modifier=1.0, prefilter_var=-1.0):
     cfg, kw = CASES[name]
     scene = synth.make_scene(cfg, seed=seed, **kw)
+    scene["scale_modifier"], scene["prefilter_var"] = scale_modifier, prefilter_var
     up = synth.make_upstream_grads(scene["W"], scene["H"], seed=seed + 100, scale=1e-2)
     ref, refg = run_oracle(scene, up, kind="reference")
     out, outg = run_oracle(scene, up, kind="port")
