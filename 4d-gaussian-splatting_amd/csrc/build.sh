@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-ARCH=${FDGS_ARCH:-gfx950}
+ARCH=${FDGS_ARCH:-gfx950}   # gfx950 only: colour_batch_kernel takes ~75 KB of static LDS (160 KB per CU here; a 64 KB-LDS target does not build)
 OUT=libfdgs.so
 if [[ "${1:-}" == "clean" ]]; then rm -rf build "$OUT"; exit 0; fi
 mkdir -p build

@@ -431,6 +431,9 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 
 	// the forward's tile order (left in the image buffer by the scan); not there for P == 0 (returned above) or with FDGS_TILE_ORDER=0
 	static const bool bwd_order = []() { const char* e = getenv("FDGS_TILE_ORDER"); return !(e && e[0] == '0'); }();
+	if (out->stage_mask < 0 || out->stage_mask > 5 || ((out->stage_mask & 4) && out->stage_mask != 5))
+		return fail(FDGS_ERR_INVALID_ARG, "stage_mask %d: 0 / 3 (whole backward), 1 (blend + SH backward), 2 (geometry backward) or 5 (blend backward only; "
+		            "the SH backward is left to fdgs_sh_backward_batch, then 2)", out->stage_mask);
 	const int stages = (out->stage_mask & 3) ? (out->stage_mask & 3) : 3;
 	if ((out->stage_mask & 4) && s.shs && !out->sh_stage)
 		return fail(FDGS_ERR_INVALID_ARG, "stage_mask + 4 (SH backward left to fdgs_sh_backward_batch) needs sh_stage");

@@ -52,6 +52,10 @@ namespace fdgs
 
 	// Tile binning (tilebin.hip): one instance counter per tile, padded to whole uint4s
 	static inline size_t bin_counter_words(int T) { return ((size_t)T + 3) & ~(size_t)3; }
+	// The tile-order area (ImageLayout::tile_order, 3 T + 16 words): [0, T) the order; at align4(T) the scan's copy of the tile
+	// counts (whole uint4 stores: the offset is a multiple of 4 words for every T); behind it T words of scratch
+	__host__ __device__ static inline int tile_order_counts_off(int T) { return (T + 3) & ~3; }
+	__host__ __device__ static inline int tile_order_tmp_off(int T) { return 2 * ((T + 3) & ~3) + 4; }
 
 	struct ImageLayout
 	{
@@ -60,7 +64,7 @@ namespace fdgs
 		size_t bin_ctl;         // { R, longest tile list } written by the scan, read back by the host
 		size_t tile_order;      // [T] the order in which the blend kernels take the tiles (longest lists first inside every XCD's
 		                        // band of tiles), written by one workgroup of the scatter launch from the
-		                        // [T] counts the scan leaves behind it (at + T); [T] words of scratch at + 2 T + 4
+		                        // [T] counts the scan leaves behind it (tile_order_counts_off); [T] words of scratch behind those
 		size_t total;
 	};
 	static inline ImageLayout image_layout(int W, int H)
@@ -74,7 +78,7 @@ namespace fdgs
 		L.ranges = o; o = align_up(o + t * 8);
 		L.tile_counters = o; o = align_up(o + bin_counter_words((int)t) * 4);
 		L.bin_ctl = o; o = align_up(o + 16);
-		L.tile_order = o; o = align_up(o + (3 * t + 8) * 4);
+		L.tile_order = o; o = align_up(o + (3 * t + 16) * 4);
 		L.total = o;
 		return L;
 	}
@@ -117,7 +121,7 @@ namespace fdgs
 	// scatter its end.  ctl[0] = R, ctl[1] = longest tile list.
 	hipError_t launch_tile_count(const uint16_t* rect, int P, int grid_x, int T, uint32_t* counters, hipStream_t stream);
 	// host_box (optional): device pointer of a pinned host mailbox {R, longest, ticket} the kernel writes directly
-	// tile_order (optional, 3 T + 8 words, see ImageLayout): the scan leaves a copy of the tile counts at tile_order + T
+	// tile_order (optional, 3 T + 16 words, see ImageLayout): the scan leaves a copy of the tile counts at tile_order + tile_order_counts_off(T)
 	hipError_t launch_tile_scan(uint32_t* counters, int T, uint32_t* ctl, uint32_t* host_box, uint32_t ticket, uint32_t* tile_order, hipStream_t stream);
 	// scatter / sort may be launched before the host knows num_rendered: they compare ctl[0] with `capacity` (the instances
 	// pairs / point_list hold) and leave everything alone -- the sort reports every tile empty -- when it does not fit

@@ -185,21 +185,20 @@ namespace fdgs
 	// fdgs_forward_out.tile_cull: the tiles of the reference's rectangle (the square of 3 sigma_max around the mean,
 	// auxiliary.h:46-57) that the Gaussian can actually reach.  alpha = min(0.99, opacity * exp(-q(d))) with q(d) = 0.5 d^T K d,
 	// K = the conic AS STORED (fp32), passes the blend's test alpha >= 1/255 (forward.cu:590) only where q(d) <= ln(255 opacity).
-	// The ellipse q <= tau has the axis-aligned extents |dx| <= sqrt(2 tau S_xx), |dy| <= sqrt(2 tau S_yy), S = K^-1.  K is the
-	// rounded (cz, -cy, cx) / det with det = cx cz - cy^2 as fp32 computed it, so S = (cx, cy, cz) * det / D with D the EXACT
-	// determinant of the fp32 numbers (in double: an elongated splat cancels most of det's bits, and S with them).  Slack: 0.05 in
-	// tau (5 % in alpha, as the blend kernels' block test: covers every rounding of the per-pixel evaluation), 0.1 % + half a
-	// pixel on the extents.  Opacity below 1/255: alpha < 1/255 everywhere, listed nowhere.  Anything odd: the reference's rectangle.
-	__device__ __forceinline__ ushort4 reachable_rect(const ushort4 ref, const float2 pix, const float3 conic, const float opacity,
-	                                                  const float cx, const float cy, const float cz, const float det)
+	// The ellipse q <= tau has the axis-aligned extents |dx| <= sqrt(2 tau S_xx), |dy| <= sqrt(2 tau S_yy) with S = K^-1 =
+	// (K_yy, -K_xy, K_xx) / D_K, D_K = K_xx K_yy - K_xy^2 evaluated in DOUBLE from the three stored fp32 numbers (their products
+	// are exact in double, so the difference keeps every bit an elongated splat cancels): S is the exact inverse of the matrix the
+	// blend kernels evaluate, whatever rounding the conic's entries went through on their way into the record.  Slack: 0.05 in tau
+	// (5 % in alpha, as the blend kernels' block test: covers every rounding of the per-pixel evaluation), 0.1 % + half a pixel on
+	// the extents.  Opacity below 1/255: alpha < 1/255 everywhere, listed nowhere.  Anything odd: the reference's rectangle.
+	__device__ __forceinline__ ushort4 reachable_rect(const ushort4 ref, const float2 pix, const float3 conic, const float opacity)
 	{
 		if (opacity < 1.0f / 255.0f) return make_ushort4(0, 0, 0, 0);
 		if (!(conic.x > 0.0f && conic.z > 0.0f)) return ref;
-		const double D = (double)cx * (double)cz - (double)cy * (double)cy;
-		if (!(D > 0.0) || !(det > 0.0f)) return ref;
-		const float ratio = (float)((double)det / D);
-		const float tau2 = 2.0f * (logf(255.0f * opacity) + 0.05f);
-		const float hx = sqrtf(tau2 * cx * ratio) * 1.001f + 0.5f, hy = sqrtf(tau2 * cz * ratio) * 1.001f + 0.5f;
+		const double DK = (double)conic.x * (double)conic.z - (double)conic.y * (double)conic.y;
+		if (!(DK > 0.0)) return ref;
+		const double tau2 = 2.0 * ((double)logf(255.0f * opacity) + 0.05);
+		const float hx = (float)sqrt(tau2 * (double)conic.z / DK) * 1.001f + 0.5f, hy = (float)sqrt(tau2 * (double)conic.x / DK) * 1.001f + 0.5f;
 		if (!(hx < 1.0e6f && hy < 1.0e6f)) return ref;   // also NaN
 		// tile t holds the pixel centres TILE * t .. TILE * t + TILE - 1: those with a centre inside [pix - h, pix + h]
 		const int tx0 = max((int)ref.x, (int)ceilf((pix.x - hx - (float)(TILE_X - 1)) / (float)TILE_X));
@@ -355,7 +354,7 @@ namespace fdgs
 						tiles = (uint32_t)((y1 - y0) * (x1 - x0));   // the reference's count, whatever the lists hold
 						rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
 						depth = p_view.z;
-						if (a.tile_cull) rect = reachable_rect(rect, pix, conic, opacity, cx, cy, cz, det);
+						if (a.tile_cull) rect = reachable_rect(rect, pix, conic, opacity);
 					}
 				}
 			}

@@ -142,13 +142,13 @@ namespace fdgs
 	                                                             int grid_x, int T, int rounds /* batch = rounds * BIN_T Gaussians per workgroup */,
 	                                                             uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
 	                                                             const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                             uint32_t* __restrict__ order /* [3 T + 8] or NULL */, int band)
+	                                                             uint32_t* __restrict__ order /* [3 T + 16] or NULL */, int band)
 	{
 		extern __shared__ uint32_t s_hist[];   // max(T, 8 * ORDER_BUCKETS) words
 		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
 		{
 			// the extra workgroup of the scatter launch: the blend kernels' tile order from the scan's copy of the counts
-			tile_order_block(order + T, order + 2 * T + 4, T, band, ctl[1], order, s_hist);
+			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, band, ctl[1], order, s_hist);
 			return;
 		}
 		// launched before the host knew num_rendered (capi.hip): `pairs` holds `capacity` instances -- more than that: leave everything alone
@@ -221,7 +221,7 @@ namespace fdgs
 		__shared__ uint32_t s_cls[8 * ORDER_BUCKETS];
 		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
 		{
-			tile_order_block(order + T, order + 2 * T + 4, T, band, ctl[1], order, s_cls);
+			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, band, ctl[1], order, s_cls);
 			return;
 		}
 		if (SCATTER && ctl[0] > capacity) return;
@@ -289,7 +289,7 @@ namespace fdgs
 			o.z = run; run += v.z;
 			o.w = run; run += v.w;
 			*p = o;
-			if (counts_copy) *reinterpret_cast<uint4*>(counts_copy + first + i) = v;   // 16-byte aligned, 3 words of slack behind T
+			if (counts_copy) *reinterpret_cast<uint4*>(counts_copy + first + i) = v;   // 16-byte aligned (tile_order_counts_off), 3 words of slack behind T
 		}
 		if (threadIdx.x == 0)
 		{
@@ -655,7 +655,7 @@ namespace fdgs
 	{
 		const int per_thread = div_up(div_up(T, SCAN_T), 4) * 4;
 		hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_T), 0, stream, counters, T, per_thread, ctl, host_box, ticket,
-		                   tile_order ? tile_order + T : nullptr);
+		                   tile_order ? tile_order + tile_order_counts_off(T) : nullptr);
 		return hipGetLastError();
 	}
 

@@ -157,7 +157,8 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
           opacity_reset_interval: int = 3000, densify_grad_threshold: float = 2e-4, densify_grad_t_threshold: float = 2e-4 / 40,
           thresh_opa_prune: float = 0.005, percent_dense: float = 0.01, cameras_extent: Optional[float] = None,
           densify_until_num_points: int = -1, on_densify: Optional[Callable] = None, log_every: int = 0,
-          log: Callable[[str], None] = print, spatial_order: bool = True) -> Dict[str, List[float]]:
+          log: Callable[[str], None] = print, spatial_order: bool = True,
+          on_resort: Optional[Callable] = None) -> Dict[str, List[float]]:
     """The reference's training loop (train.py:82-254) over ``cameras`` / ``gts`` (all views, identical on every rank;
     each rank renders its FrameShard slice).  Returns the logged history {"iteration", "loss", "psnr"}.
     Densification (train.py:229-244) runs when ``cameras_extent`` is given: every rank takes the same decisions from the
@@ -170,11 +171,15 @@ def train(model, optimizer, cameras: Sequence, gts: Sequence[torch.Tensor], pipe
     reference's extra opacity reset at ``densify_from_iter`` (train.py:243).
     ``spatial_order``: the model is kept in Morton order of the Gaussians' positions (train_host.spatial_sort: at the start and
     after every densification, when the statistics have just been reset) -- a memory-layout choice with no effect on the
-    arithmetic; every rank derives the same permutation from its (identical) parameters."""
+    arithmetic; every rank derives the same permutation from its (identical) parameters.  NOTE: the caller's ``model`` and the
+    optimizer's moments are REORDERED IN PLACE (row j becomes the old row perm[j]); a caller that keeps per-Gaussian side data
+    indexed like the model passes ``spatial_order=False`` or applies ``on_resort(perm)`` to it (called with every permutation)."""
     from .train_host import spatial_sort
 
     def resort(stats=None):
         perm = spatial_sort(model, optimizer)
+        if on_resort is not None:
+            on_resort(perm)
         if stats is not None:   # everything else that is indexed by Gaussian follows the model
             stats.xyz_gradient_accum, stats.t_gradient_accum = stats.xyz_gradient_accum[perm], stats.t_gradient_accum[perm]
             stats.denom, stats.max_radii2D = stats.denom[perm], stats.max_radii2D[perm]

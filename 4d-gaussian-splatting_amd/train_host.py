@@ -361,6 +361,8 @@ def morton_permutation(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
     """Permutation (on xyz's device) that puts points into Morton (Z-order) order of their positions quantised to ``bits`` bits
     per axis; ties keep their order (stable), so the result is a pure function of the positions."""
     p = xyz.detach().double()
+    if p.shape[0] == 0:   # everything pruned: nothing to order (min / max over an empty dimension raise)
+        return torch.arange(0, dtype=torch.long, device=p.device)
     lo, hi = p.min(0).values, p.max(0).values
     q = ((p - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
     code = torch.zeros(p.shape[0], dtype=torch.long, device=p.device)
