@@ -24,7 +24,7 @@ FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
 _fp = C.c_void_p  # all device pointers travel as void*
 
 
-FDGS_VERSION = 310  # include/fdgs.h; checked against fdgs_version() at import
+FDGS_VERSION = 400  # include/fdgs.h; checked against fdgs_version() at import
 
 
 class _Sized(C.Structure):
@@ -52,7 +52,8 @@ class FdgsScene(_Sized):
 
 class FdgsForwardOut(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
-                ("out_means3D", _fp), ("covs_com", _fp), ("preprocessed", C.c_int32), ("split_colour", C.c_int32), ("tile_cull", C.c_int32)]
+                ("out_means3D", _fp), ("covs_com", _fp), ("preprocessed", C.c_int32), ("split_colour", C.c_int32), ("tile_cull", C.c_int32),
+                ("lazy", C.c_int32)]
 
 
 class FdgsBackwardIn(_Sized):
@@ -82,7 +83,7 @@ class FdgsAdamSegment(C.Structure):
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
-EXPORTED = ("fdgs_rasterize_forward", "fdgs_rasterize_backward", "fdgs_preprocess_batch", "fdgs_sh_backward_batch", "fdgs_mark_visible", "fdgs_geometry_bytes",
+EXPORTED = ("fdgs_rasterize_forward", "fdgs_forward_lazy_status", "fdgs_rasterize_backward", "fdgs_preprocess_batch", "fdgs_sh_backward_batch", "fdgs_mark_visible", "fdgs_geometry_bytes",
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
@@ -98,6 +99,9 @@ def _load():
     lib.fdgs_rasterize_forward.argtypes = [C.POINTER(FdgsScene), C.POINTER(FdgsForwardOut), ALLOC_FN, C.c_void_p,
                                            C.c_void_p, C.POINTER(C.c_int32)]
     lib.fdgs_rasterize_forward.restype = C.c_int
+    lib.fdgs_forward_lazy_status.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.c_int32, C.POINTER(C.c_int32)]
+    lib.fdgs_forward_lazy_status.restype = C.c_int
     lib.fdgs_rasterize_backward.argtypes = [C.POINTER(FdgsScene), C.POINTER(FdgsBackwardIn),
                                             C.POINTER(FdgsBackwardOut), C.c_void_p]
     lib.fdgs_rasterize_backward.restype = C.c_int
@@ -258,6 +262,16 @@ def adam_step_sh(params, exp_avg, exp_avg_sq, stages, sh_degree, sh_degree_t, ga
                                    current_stream_handle(params.device))
     _check(rc, "fdgs_adam_step_sh")
     return True
+
+
+def forward_lazy_status(device, wait=True):
+    """fdgs_forward_lazy_status for the calling thread on ``device``: (pending, failed, [num_rendered of the reported forwards])."""
+    pend, failed, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    rs = (C.c_int32 * 64)()
+    with torch.cuda.device(device):
+        rc = lib.fdgs_forward_lazy_status(int(bool(wait)), current_stream_handle(device), C.byref(pend), C.byref(failed), rs, 64, C.byref(n))
+    _check(rc, "fdgs_forward_lazy_status")
+    return int(pend.value), int(failed.value), [int(rs[i]) for i in range(n.value)]
 
 
 def run_ahead_stats():

@@ -177,12 +177,103 @@ extern "C" int fdgs_version(void) { return FDGS_VERSION; }
 // again (longer lists than guessed), [2] exact sizes (first call of a thread, debug mode, or more instances than guessed)
 static std::atomic<long long> g_run_ahead[3];
 static std::atomic<bool> g_run_ahead_enabled{true};
-constexpr int FDGS_MAX_DEVICES = 64;
-constexpr int FDGS_GUESS_SLOTS = 8;
+constexpr int FDGS_MAX_DEVICES = 64;   // = the size of g_box_of
+constexpr int FDGS_GUESS_SLOTS = 8;    // = the size of g_guesses
 extern "C" void fdgs_set_run_ahead(int32_t enable) { g_run_ahead_enabled.store(enable != 0); }
 extern "C" void fdgs_debug_run_ahead_stats(int64_t* counts3)
 {
 	for (int k = 0; k < 3; k++) counts3[k] = (int64_t)g_run_ahead[k].load();
+}
+
+// ---- per host thread and device: the pinned mailbox ring the tile scans report into, the run-ahead guesses, the lazy forwards ----
+namespace
+{
+	constexpr int MAIL_SLOTS = 64;   // forwards of one thread that may be unreported at a time (fdgs_forward_out.lazy); 16 bytes each
+	struct RunAhead { int dev = -1, W = 0, H = 0, P = 0; long long capacity = 0; int longest = 0; long long r_hist[4] = { 0, 0, 0, 0 }; int l_hist[4] = { 0, 0, 0, 0 }; int hist_at = 0; };
+	struct MailRec { unsigned long long seq = 0; long long cap = 0; int longest_cap = 0; RunAhead* guess = nullptr; int gdev = 0, gW = 0, gH = 0, gP = 0; bool pending = false, lazy = false; };
+	struct Mailbox
+	{
+		volatile uint32_t* host = nullptr; uint32_t* dev = nullptr;
+		unsigned long long seq = 0, head = 1;   // last sequence number handed out; oldest one that may still be pending
+		MailRec rec[MAIL_SLOTS];
+		int failed = 0;                         // lazy forwards whose lists did not fit, since the last fdgs_forward_lazy_status
+		int done_R[MAIL_SLOTS]; int done_n = 0; // num_rendered of the lazy forwards reported since then (oldest first)
+	};
+	thread_local Mailbox* g_box_of[64];   // allocated on a thread's first forward on the device
+	thread_local RunAhead g_guesses[8];
+	thread_local int g_guess_next = 0;
+	inline uint32_t ticket_of(unsigned long long seq) { return (uint32_t)(seq % 0xFFFFFFFFull) + 1u; }   // never 0
+
+	void note_result(RunAhead& g, long long R, int longest)
+	{
+		g.capacity = std::min<long long>(R + R / 4 + 4096, 0x7fffffffLL);
+		g.longest = longest + longest / 4;
+		g.r_hist[g.hist_at & 3] = R; g.l_hist[g.hist_at & 3] = longest; g.hist_at++;
+	}
+	// Reads the reports of this thread's pending forwards, oldest first.  wait: block until all of them (or, with upto != 0, all
+	// up to that sequence number) are in; otherwise stop at the first one that has not reported.  stream (optional): polled now and
+	// then while waiting, so that a failed launch ends the wait.  Returns false when a report never showed up.
+	bool harvest(Mailbox& box, bool wait, unsigned long long upto, hipStream_t stream, bool have_stream)
+	{
+		while (box.head <= box.seq && (upto == 0 || box.head <= upto))
+		{
+			MailRec& r = box.rec[box.head % MAIL_SLOTS];
+			if (!r.pending || r.seq != box.head) { box.head++; continue; }
+			volatile uint32_t* m = box.host + 4 * (box.head % MAIL_SLOTS);
+			const uint32_t want = ticket_of(r.seq);
+			bool arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want;
+			if (!arrived && !wait) return true;
+			for (long spin = 0; !arrived && spin < 2000000000L; spin++)   // bounded: tens of seconds
+			{
+				arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want;
+				if (!arrived && have_stream && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(stream) != hipErrorNotReady)
+				{
+					arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want;
+					break;
+				}
+			}
+			if (!arrived) return false;
+			const long long R = (long long)(int)m[0];
+			const int longest = (int)m[1];
+			if (r.guess && r.guess->dev == r.gdev && r.guess->W == r.gW && r.guess->H == r.gH && r.guess->P == r.gP) note_result(*r.guess, R, longest);
+			if (r.lazy)
+			{
+				if (R < 0 || R > r.cap || longest > r.longest_cap) box.failed++;
+				if (box.done_n < MAIL_SLOTS) box.done_R[box.done_n++] = (int)R;
+			}
+			r.pending = false;
+			box.head++;
+		}
+		return true;
+	}
+}
+
+extern "C" int fdgs_forward_lazy_status(int32_t wait, void* stream_v, int32_t* pending, int32_t* failed, int32_t* num_rendered, int32_t max_out, int32_t* n_out)
+{
+	g_err[0] = 0;
+	int dev_id = 0;
+	HIP_TRY(hipGetDevice(&dev_id), "hipGetDevice");
+	if (dev_id < 0 || dev_id >= 64) return fail(FDGS_ERR_UNSUPPORTED, "device ordinal %d beyond 64", dev_id);
+	if (!g_box_of[dev_id])
+	{
+		if (pending) *pending = 0;
+		if (failed) *failed = 0;
+		if (n_out) *n_out = 0;
+		return FDGS_OK;
+	}
+	Mailbox& box = *g_box_of[dev_id];
+	if (box.host && !harvest(box, wait != 0, 0, (hipStream_t)stream_v, stream_v != nullptr))
+		return fail(FDGS_ERR_HIP, "a lazy forward never reported num_rendered (failed launch?)");
+	int left = 0;
+	for (unsigned long long q = box.head; q <= box.seq; q++) if (box.rec[q % MAIL_SLOTS].pending && box.rec[q % MAIL_SLOTS].seq == q) left++;
+	if (pending) *pending = left;
+	if (failed) *failed = box.failed;
+	const int n = num_rendered ? std::min(box.done_n, (int)std::max(max_out, 0)) : 0;
+	for (int i = 0; i < n; i++) num_rendered[i] = box.done_R[i];
+	if (n_out) *n_out = n;
+	box.failed = 0;
+	box.done_n = 0;
+	return FDGS_OK;
 }
 
 extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
@@ -271,23 +362,29 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	const float* depths = (const float*)(geom + GL.depths);
 	STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
 	// num_rendered (and the longest tile list) come back through a pinned, device-mapped mailbox that the scan kernel
-	// writes itself: {R, longest, ticket}.  The host spins on the ticket -- the forward's one wait for the device, as
-	// rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the ticket does not show up
-	// (a failed launch), the stream is synchronised and the error reported.
-	struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t ticket = 0; };
-	static thread_local Mailbox box_of[FDGS_MAX_DEVICES];
-	Mailbox& box = box_of[dev_id];
+	// writes itself: {R, longest, ticket}, one slot of a small ring per forward.  The host spins on the ticket -- the forward's
+	// one wait for the device, as rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the
+	// ticket does not show up (a failed launch), the stream is synchronised and the error reported.  A LAZY forward
+	// (fdgs_forward_out.lazy) does not wait at all: its report is read by a later call (fdgs_forward_lazy_status, or the next forward).
+	if (!g_box_of[dev_id]) g_box_of[dev_id] = new Mailbox();
+	Mailbox& box = *g_box_of[dev_id];
 	if (!box.host)
 	{
 		void* h = nullptr;
-		HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped), "hipHostMalloc");
-		memset(h, 0, 64);
+		HIP_TRY(hipHostMalloc(&h, MAIL_SLOTS * 16, hipHostMallocMapped), "hipHostMalloc");
+		memset(h, 0, MAIL_SLOTS * 16);
 		void* d = nullptr;
 		HIP_TRY(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
 		box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
 	}
-	const uint32_t ticket = ++box.ticket ? box.ticket : ++box.ticket;   // never 0
-	STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev, ticket, tile_order, stream), "tile scan");
+	// reports that are in by now refresh the guesses; the slot this call takes must be free (at most MAIL_SLOTS unreported forwards)
+	if (!harvest(box, false, 0, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
+	const unsigned long long seq = ++box.seq;
+	if (seq >= MAIL_SLOTS && !harvest(box, true, seq - MAIL_SLOTS, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
+	const int slot = (int)(seq % MAIL_SLOTS);
+	const uint32_t ticket = ticket_of(seq);
+	volatile uint32_t* const mail = box.host + 4 * slot;
+	STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev + 4 * slot, ticket, tile_order, stream), "tile scan");
 
 	// Run-ahead.  The reference stops here until num_rendered has come back and sizes the binning buffers with it
 	// (rasterizer_impl.cu:302-306): the device idles for a host round trip in the middle of the forward.  Views follow each
@@ -298,23 +395,34 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	// the scatter pass with exact sizes.
 	// the guess is kept per (device, image size, P): a thread that alternates between scenes or resolutions keeps one per
 	// configuration (a few slots, replaced round-robin)
-	struct RunAhead { int dev = -1, W = 0, H = 0, P = 0; long long capacity = 0; int longest = 0; };
-	static thread_local RunAhead guesses[FDGS_GUESS_SLOTS];
-	static thread_local int guess_next = 0;
 	RunAhead* gp = nullptr;
-	for (auto& g : guesses) if (g.dev == dev_id && g.W == W && g.H == H && g.P == P) gp = &g;
+	for (auto& g : g_guesses) if (g.dev == dev_id && g.W == W && g.H == H && g.P == P) gp = &g;
 	if (!gp)
 	{
-		gp = &guesses[guess_next];
-		guess_next = (guess_next + 1) % FDGS_GUESS_SLOTS;
+		gp = &g_guesses[g_guess_next];
+		g_guess_next = (g_guess_next + 1) % FDGS_GUESS_SLOTS;
 		*gp = RunAhead();
 		gp->dev = dev_id; gp->W = W; gp->H = H; gp->P = P;
 	}
 	RunAhead& guess = *gp;
+	MailRec& rec = box.rec[slot];
+	rec = MailRec();
+	rec.seq = seq; rec.guess = gp; rec.gdev = dev_id; rec.gW = W; rec.gH = H; rec.gP = P; rec.pending = true;
 	const int lds_cap = tile_sort_lds_cap();
 	const bool ahead = guess.capacity > 0 && !debug && g_run_ahead_enabled.load(std::memory_order_relaxed);
-	const long long ahead_cap = guess.capacity;
-	const int ahead_longest = guess.longest;
+	// lazy: nobody is there to start over, so the headroom is generous -- 1.5 x the largest of the last four reports (+ 64 Ki
+	// instances, in steps of 256 Ki so that the allocator sees few distinct sizes), and the sort instances are chosen for lists
+	// 1.5 x the longest one seen; a forward that still does not fit is reported by fdgs_forward_lazy_status
+	const bool lazy = ahead && out->lazy != 0;
+	long long ahead_cap = guess.capacity;
+	int ahead_longest = guess.longest;
+	if (lazy)
+	{
+		long long rmax = 0; int lmax = 0;
+		for (int k = 0; k < 4; k++) { rmax = std::max(rmax, guess.r_hist[k]); lmax = std::max(lmax, guess.l_hist[k]); }
+		ahead_cap = std::min<long long>((((rmax + rmax / 2 + 65536) >> 18) + 1) << 18, 0x7fffffffLL);
+		ahead_longest = lmax + lmax / 2 + 64;
+	}
 	char* bin = nullptr;
 	BinLayout BL = bin_layout(0, false);
 	bool has_scratch = false;   // BL includes the global sort scratch
@@ -339,25 +447,23 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		if ((rc = enqueue_rest(ahead_cap, ahead_longest, true)) != FDGS_OK) return rc;
 	}
 
+	if (lazy)
 	{
-		bool arrived = false;
-		for (long spin = 0; spin < 400000000L && !arrived; spin++)   // bounded: seconds
-		{
-			arrived = __atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) == ticket;
-			// now and then: has the stream drained (or failed) without the ticket showing up?  then stop spinning
-			if (!arrived && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(stream) != hipErrorNotReady) break;
-		}
-		if (!arrived)
-		{
-			HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
-			if (__atomic_load_n(&box.host[2], __ATOMIC_ACQUIRE) != ticket) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
-		}
+		// everything is on its way; the report is read later (the slot stays pending)
+		rec.lazy = true; rec.cap = ahead_cap; rec.longest_cap = ahead_longest;
+		*num_rendered = -1;
+		g_run_ahead[0]++;
+		return FDGS_OK;
 	}
-	const int R = (int)box.host[0], longest = (int)box.host[1];
+	// this call's own report (older pending ones -- lazy forwards -- are read on the way)
+	if (!harvest(box, true, seq, stream, true))
+	{
+		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
+		if (!harvest(box, true, seq, stream, false)) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
+	}
+	const int R = (int)mail[0], longest = (int)mail[1];
 	if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
 	*num_rendered = R;
-	guess.capacity = std::min<long long>((long long)R + R / 4 + 4096, 0x7fffffffLL);
-	guess.longest = longest + longest / 4;
 
 	if (ahead && R <= ahead_cap && longest <= ahead_longest) { g_run_ahead[0]++; return FDGS_OK; }   // the usual case: everything is already on its way
 	if (ahead && R <= ahead_cap)
@@ -420,7 +526,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 		if (s.rot_4d && (!out->dL_dscales_t || !out->dL_drotations_r || !out->dL_dts))
 			return fail(FDGS_ERR_INVALID_ARG, "dL_dscales_t / dL_drotations_r / dL_dts must not be NULL for rot_4d");
 	}
-	const int R = in->num_rendered;
+	const int R = in->num_rendered;   // < 0: not known (a lazy forward): the tile ranges carry everything the kernels need
 	const GeomLayout GL = geom_layout(P);
 	const ImageLayout IL = image_layout(W, H);
 	const BinLayout BL = bin_layout(R, false);   // point_list sits at the front whatever else the forward asked for
@@ -442,7 +548,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 		// the packed accumulator records of the blend backward start from zero
 		if (!out->grad_accum_clean)
 			STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->grad_accum, 0, (size_t)P * GRAD_ACC_WORDS * 4, stream), "memset");
-		if (R > 0)
+		if (R != 0)
 			STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
 			                       bwd_order ? (const uint32_t*)(img + IL.tile_order) : nullptr, (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
 		if (!(out->stage_mask & 4)) STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");

@@ -27,7 +27,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stag
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
                  fuse_sh_adam: bool = True, gather_max_views: int = 32, split_colour: bool = False, batch_views: bool = False,
-                 sh_group: int = 1, tile_cull: bool = True):
+                 sh_group: int = 1, tile_cull: bool = True, lazy: bool = True):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -45,6 +45,14 @@ class StepPipeline:
         # fdgs_forward_out.tile_cull: the tile lists hold a Gaussian only where it can reach alpha >= 1/255 (same pixels and
         # gradients as with the reference's lists, a quarter fewer instances at C3)
         self.tile_cull = bool(tile_cull)
+        # fdgs_forward_out.lazy (one rank): no forward of the step waits for its num_rendered -- the host enqueues all B views without
+        # touching the device (the reference stops in the middle of every forward, rasterizer_impl.cu:302) and reads the views' reports
+        # ONCE, before the last view's backward, i.e. before anything of the optimizer step is enqueued; a view whose run-ahead buffers
+        # turned out too small (its image is invalid) sends the whole step through the waiting path again -- nothing irreversible has
+        # happened by then: the gradient bucket and the SH stages are simply overwritten.  ``lazy_redone`` counts those steps.
+        # Several ranks: off (the decision to start over would have to be collective).
+        self.lazy = bool(lazy)
+        self.lazy_redone = 0
         self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
         # View batching (opt-in, B > 1): the SH coefficients -- 12 M bytes per Gaussian, most of what preprocess and SH backward
         # read -- are the same for every view of the step.  ``batch_views``: the views' geometry still runs per view, but their SH
@@ -83,6 +91,16 @@ class StepPipeline:
         """Runs forward + loss + backward of every view, the gradient all-reduce and the optimizer step.
         Returns (list of per-view results dict(render, radii, depth, alpha_T, flow, viewspace_grad, num_rendered), list
         of losses); the tensors may be used on the caller's stream until the next call of step()."""
+        if self.lazy and self.world == 1 and not (self.sh_group > 1 and len(cams) > 1):
+            out = self._step_views(cams, gts, pipe, bg, scaling_modifier, True)
+            if out is not None:
+                return out
+            self.lazy_redone += 1
+        return self._step_views(cams, gts, pipe, bg, scaling_modifier, False)
+
+    def _step_views(self, cams, gts, pipe, bg, scaling_modifier, lazy):
+        """step(); ``lazy``: see __init__ -- returns None when a view did not fit its run-ahead buffers (nothing of the optimizer step
+        has been enqueued then)."""
         B = len(cams)
         main = torch.cuda.current_stream(self.dev)
         self.sF.wait_stream(main)
@@ -106,6 +124,7 @@ class StepPipeline:
             with torch.cuda.stream(self.sB):
                 self._gathered = torch.empty((B, self.world, m.P, 8), dtype=torch.float32, device=self.dev)
         results, losses, keep = [], [], []
+        R_last = -1
         sh_handle = []
         sh_gather = []     # gather: the work handles of the views' stage exchanges
         sh_stepped = []    # fuse: did the SH update run (on stream F) behind the last view's SH backward?
@@ -123,12 +142,28 @@ class StepPipeline:
                     cams[b], m, pipe, bg, scaling_modifier)
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
                     rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
-                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull)
+                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull, lazy=lazy and handles[b] is None)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
                 self.sB.wait_event(ev)
                 g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
+                if lazy and b == B - 1:
+                    # the one look at the device per step: did every view's lists fit?  (the last forward's tile scan has usually run
+                    # by now -- the host is about one view ahead of the device here, not inside every forward)
+                    with torch.cuda.stream(self.sF):
+                        _pend, failed, reported = _capi.forward_lazy_status(self.dev, wait=True)
+                    if failed:
+                        main.wait_stream(self.sB)
+                        main.wait_stream(self.sF)
+                        self.sF.wait_stream(self.sB)
+                        return None
+                    lazy_ix = [i for i, r_ in enumerate(results) if r_["num_rendered"] < 0] + ([b] if R < 0 else [])
+                    for i, r_val in zip(lazy_ix, reported[-len(lazy_ix):] if lazy_ix else []):
+                        if i < b:
+                            results[i]["num_rendered"] = r_val
+                        else:
+                            R_last = r_val
                 # last view of the step on several ranks: the SH gradients (88 % of the bucket) are final once this view's
                 # SH backward has run -- their all-reduce starts there and travels while the geometry backward runs
                 after_sh = None
@@ -160,7 +195,7 @@ class StepPipeline:
             # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
             keep.append((geom, binb, img, out_means3D, g_color, T))
             results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow,
-                            "viewspace_grad": grads[0], "num_rendered": R})
+                            "viewspace_grad": grads[0], "num_rendered": R_last if (lazy and b == B - 1 and R < 0) else R})
             losses.append(loss)
         self._optimizer_tail(rs, fuse, gather, sh_handle, sh_gather, sh_stepped)
         main.wait_stream(self.sB)

@@ -76,6 +76,16 @@ def parse_args():
                          "(configs/dynerf/*.yaml:7; gradients accumulated, train.py:104-166), weak scaling: global batch "
                          "4 N.  1: BASELINE configs[3] as specified (N timesteps frame-parallel across N GPUs, one view "
                          "per rank and step, one gradient all-reduce per view)")
+    ap.add_argument("--min-warmup-ms", type=float, default=150.0,
+                    help="the warm-up goes on (whole steps) until this much wall time has passed, whatever --warmup says: the shader clock "
+                         "needs ~100 ms of load to settle")
+    ap.add_argument("--min-timed-ms", type=float, default=1000.0,
+                    help="the timed region is --steps steps repeated (whole multiples) until it lasts at least this long; `steps_timed` in the "
+                         "JSON line says how many steps that was (0: exactly --steps)")
+    ap.add_argument("--reflists-steps", type=int, default=20,
+                    help="steps of the extra leg with the reference's bit-identical tile lists (tile_cull = 0): value_reference_lists (0 = skip)")
+    ap.add_argument("--no-lazy", action="store_true",
+                    help="A/B: every forward waits for its num_rendered (as the reference does) instead of fdgs_forward_out.lazy")
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
     ap.add_argument("--host-cost-steps", type=int, default=30,
                     help="steps of the tiny-scene leg that measures the host cost per view (0 = skip, e.g. under rocprofv3)")
@@ -291,7 +301,8 @@ def pmc_valu(stage):
             return None
         simds = 256 * 4
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's SIMDs (MI355X_MICROARCH.md, s_memtime row)
-        return {"insts_valu_per_launch": int(vals.get("SQ_INSTS_VALU", 0)),
+        return {"counters_from": "committed pass (not this run): " + os.path.relpath(files[-1], ROOT),
+                "insts_valu_per_launch": int(vals.get("SQ_INSTS_VALU", 0)),
                 "valu_issue_cycles_per_simd": int(vals["SQ_ACTIVE_INST_VALU"] * 4 / simds),
                 "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
@@ -336,7 +347,7 @@ def main():
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
                                 gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all", tile_cull=not args.no_tile_cull,
-                                batch_views=args.batch_views, sh_group=args.sh_group)
+                                batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy)
 
     def step():
         if use_pipeline:
@@ -362,15 +373,24 @@ def main():
         opt.step()
         return [pkg]
 
-    for _ in range(args.warmup):
+    # warm-up: --warmup steps, and on until --min-warmup-ms of wall time have passed (the driver's --warmup 5 is 15 ms of C3 steps;
+    # the shader clock takes ~100 ms of load to settle)
+    torch.cuda.synchronize(dev)
+    tw = time.perf_counter()
+    warm_steps = 0
+    while warm_steps < args.warmup or (time.perf_counter() - tw) * 1e3 < args.min_warmup_ms:
         step()
+        warm_steps += 1
+        if warm_steps >= args.warmup and warm_steps % 4 == 0:
+            torch.cuda.synchronize(dev)   # the host runs ahead of the device: measure time that has actually been worked
+    torch.cuda.synchronize(dev)
     # Untimed stage pass on ONE stream (kernel time, not queueing time behind the other stream's launches): every
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.
     if use_pipeline:
         stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
                                   gather_max_views=0 if args.dense_sh_exchange else 32, batch_views=args.batch_views, sh_group=args.sh_group,
-                                  tile_cull=not args.no_tile_cull)
-        stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)  # noqa: E731
+                                  tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+        stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)[0]  # noqa: E731
     else:
         stage_step = step
     stage_step()
@@ -378,27 +398,38 @@ def main():
     _capi.profile_reset()
     _capi.profile_enable(True)
     n_stage_steps = max(1, min(3, args.steps))
-    _R_LOG.clear()
+    r_seen = []
     for _ in range(n_stage_steps):
-        stage_step()
+        r_seen += [r["num_rendered"] for r in stage_step() if "num_rendered" in r]
     torch.cuda.synchronize(dev)
     _capi.profile_enable(False)
     prof_all = _capi.profile_read()
-    R_stage = sum(_R_LOG) / max(len(_R_LOG), 1)
+    R_stage = (sum(r_seen) / len(r_seen)) if r_seen else (sum(_R_LOG) / max(len(_R_LOG), 1))
     dom = max((k for k in prof_all if k != "readback"), key=lambda k: prof_all[k][0])
     # Timed region (the two-stream pipeline): only the dominant kernel keeps its event pair -- the roofline figure is
     # measured live here -- and one event per step boundary on the main stream gives the per-step distribution.
     _capi.profile_reset()
     _capi.profile_enable(True, stages=[dom])
     _R_LOG.clear()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # shader clock actually sustained during the timed steps: a one-wave sampler on its own stream spans ~80 % of the region
-    # (its length estimated from two more untimed steps)
+    # the timed region: --steps steps, repeated (whole multiples) until it lasts >= --min-timed-ms
     torch.cuda.synchronize(dev)
-    te = time.perf_counter()
+    te0 = time.perf_counter()
     step(); step()
     torch.cuda.synchronize(dev)
-    est_ms = (time.perf_counter() - te) / 2 * 1e3 * args.steps
+    est_step_ms = (time.perf_counter() - te0) / 2 * 1e3
+    reps = 1
+    if args.min_timed_ms > 0:
+        reps = max(1, int(-(-args.min_timed_ms // max(est_step_ms * args.steps, 1e-3))))
+    if world > 1:   # every rank must time the same number of steps
+        import torch.distributed as dist
+        t_reps = torch.tensor([reps], dtype=torch.int64, device=dev)
+        dist.all_reduce(t_reps, op=dist.ReduceOp.MAX)
+        reps = int(t_reps.item())
+    steps_timed = reps * args.steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps_timed + 1)]
+    # shader clock actually sustained during the timed steps: a one-wave sampler on its own stream spans ~80 % of the region
+    # (its length estimated from two more untimed steps)
+    est_ms = est_step_ms * steps_timed
     clock = None
     try:
         clock = _capi.ClockSample(dev)
@@ -415,7 +446,7 @@ def main():
     marks[0].record()
     if clock is not None:
         clock.start(min(max(0.8 * est_ms, 1.0), 1500.0))
-    for i in range(args.steps):
+    for i in range(steps_timed):
         pkg = step()
         marks[i + 1].record()
     torch.cuda.synchronize(dev)
@@ -430,8 +461,10 @@ def main():
         shader_ghz = None
     prof_dom = _capi.profile_read()[dom]
     dt = max_over_ranks(dt, world, dev)
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    R_timed = sum(_R_LOG) / max(len(_R_LOG), 1)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps_timed))
+    r_last = [r["num_rendered"] for r in pkg if isinstance(r, dict) and r.get("num_rendered", -1) >= 0]
+    R_timed = (sum(r_last) / len(r_last)) if r_last else (sum(_R_LOG) / max(len(_R_LOG), 1))
+    lazy_redone = steppipe.lazy_redone if use_pipeline else None
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]  # noqa: E731
 
     # digest of the parameters after all steps (tests compare N ranks x B views with one rank x N B views: the same update)
@@ -447,15 +480,17 @@ def main():
         replicas_identical = bool(torch.equal(lo, hi))
 
     # forward-only rate (the metric's second half), outside the train-step timing
-    n_fwd = args.steps * B
+    n_fwd = min(steps_timed, 4 * args.steps) * B
 
     def forward_only(c):
         if use_pipeline:  # the same explicit call the step pipeline makes (no autograd bookkeeping)
             from fdgs.fused import raw_forward, raw_settings
             rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
             return raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
-                               split_colour=args.split_colour != "off", tile_cull=not args.no_tile_cull)
+                               split_colour=args.split_colour != "off", tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
         return render(c, model, pipe, bg) if args.reference_host else render_raw(c, model, pipe, bg)
+
+    fwd_lazy_failed = 0
 
     with torch.no_grad():
         for _ in range(20):   # right behind the timed steps (the shader clock is up); a few more calls settle the allocator on this stream
@@ -469,8 +504,12 @@ def main():
             t1 = time.perf_counter()
             for i in range(per):
                 forward_only(cams[(s_ * per + i) % B])
+                if i % 32 == 31 and use_pipeline and not args.no_lazy:
+                    fwd_lazy_failed += _capi.forward_lazy_status(dev, wait=False)[1]   # keeps the ring of unreported forwards short
             torch.cuda.synchronize(dev)
             slices.append(time.perf_counter() - t1)
+            if use_pipeline and not args.no_lazy:
+                fwd_lazy_failed += _capi.forward_lazy_status(dev, wait=True)[1]
         n_fwd = 5 * per
         dt_fwd = max_over_ranks(sorted(slices)[2] * 5, world, dev)
 
@@ -507,6 +546,27 @@ def main():
         raster = {"images_s": round(n_fwd / dt_r, 2), "ms_per_image": round(dt_r / n_fwd * 1e3, 4),
                   "what": "rasterizer forward + backward only (all four upstream gradients given), one stream, %d views: pairs with cpu_baseline" % n_fwd}
         del gacc, up4
+
+    # the same step with the reference's tile lists (fdgs_forward_out.tile_cull = 0: point_list / ranges / n_contrib bit-identical to the
+    # reference's) -- `value` runs with tile_cull = 1 (same pixels and gradients, a quarter fewer list entries)
+    reflists = None
+    if use_pipeline and args.reflists_steps > 0 and not args.no_tile_cull:
+        rp = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
+                          gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy)
+        for _ in range(3):
+            rp.step(cams, gts, pipe, bg)
+        torch.cuda.synchronize(dev)
+        barrier(world)
+        tr0 = time.perf_counter()
+        for _ in range(args.reflists_steps):
+            rres, _l = rp.step(cams, gts, pipe, bg)
+        torch.cuda.synchronize(dev)
+        barrier(world)
+        dtr = max_over_ranks(time.perf_counter() - tr0, world, dev)
+        reflists = {"images_s": round(world * B * args.reflists_steps / dtr, 2), "ms_per_step": round(dtr / args.reflists_steps * 1e3, 4),
+                    "steps": args.reflists_steps, "num_rendered": int(round(sum(r["num_rendered"] for r in rres) / len(rres))),
+                    "what": "the same step with tile_cull = 0: the tile lists are the reference's, bit for bit (tests/test_gpu_parity.py)"}
+        del rp
 
     # the same step with the model stored in Morton order (a memory-layout choice of the trainer, no effect on the arithmetic)
     spatial = None
@@ -589,6 +649,7 @@ def main():
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
+                "traffic_source": "committed rocprofv3 --pmc passes of the same command (profiles/pmc_traffic_r*.json, tools/pmc_traffic.py), not this run",
                 "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"],
                 "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
@@ -608,12 +669,17 @@ def main():
             "BASELINE configs[3] as specified: one view per GPU and step, N timesteps frame-parallel")
     out = {
         "metric": "train-step images/sec + forward Mpix/s, 300k 4D Gaussians @1352x1014",
-        "value": round(world * B * args.steps / dt, 3),
+        "value": round(world * B * steps_timed / dt, 3),
         "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        # the timed region is --steps steps repeated `steps_timed / steps` times (>= --min-timed-ms of wall time), one barrier +
+        # synchronize pair around all of it; the warm-up ran `warmup_steps_run` steps (>= --warmup, >= --min-warmup-ms)
+        "steps_timed": steps_timed, "warmup_steps_run": warm_steps, "timed_region_ms": round(dt * 1e3, 2),
+        "value_median": round(world * B * 1e3 / pct(0.5), 3),
+        "ms_per_step": round(dt / steps_timed * 1e3, 4),
         "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4),
-        "ms_per_image": round(dt / (args.steps * B) * 1e3, 4),
+        "ms_per_image": round(dt / (steps_timed * B) * 1e3, 4),
+        "lazy_forward": bool(use_pipeline and not args.no_lazy and world == 1), "lazy_steps_redone": lazy_redone,
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,
         "dtype": "f32", "data": "synthetic",
@@ -625,6 +691,7 @@ def main():
         "forward_mpix_s": round(world * n_fwd * N / dt_fwd / 1e6, 1),
         "forward_split_colour": bool(use_pipeline and args.split_colour != "off"),
         "forward_ms": round(dt_fwd / n_fwd * 1e3, 4),
+        "forward_lazy_failed": fwd_lazy_failed,   # forwards of the forward-only leg whose run-ahead buffers were too small (their images are invalid): must be 0
         "raster_ms": round(sum(v["ms"] for v in stages.values()), 4),
         "live_gaussians": int(round(P_live)),
         "stages": stages,
@@ -636,6 +703,9 @@ def main():
     }
     out["rccl_ranks"] = world
     out["backend"] = backend if backend else "none (single process)"
+    if reflists:
+        out["value_reference_lists"] = reflists["images_s"]
+        out["reference_lists"] = reflists
     if spatial:
         out["spatial_order_images_s"] = spatial["images_s"]
         out["spatial_order"] = spatial

@@ -31,8 +31,9 @@
  *    Appendix A, Q1-Q13).
  *
  * Threading contract.  All work is enqueued on the caller's `stream`; fdgs_rasterize_forward waits for the device once
- * (for num_rendered, as the reference does at rasterizer_impl.cu:302): it spins on a pinned mailbox the tile-scan kernel
- * writes.  The library keeps, PER HOST THREAD AND DEVICE: the last-error string, that pinned mailbox, a second stream with
+ * (for num_rendered, as the reference does at rasterizer_impl.cu:302; not at all with fdgs_forward_out.lazy): it spins on a pinned
+ * mailbox the tile-scan kernel writes.  The library keeps, PER HOST THREAD AND DEVICE: the last-error string, that pinned mailbox
+ * (a ring of 64 slots: at most 64 lazy forwards of a thread are unreported at a time; the 65th waits for the oldest), a second stream with
  * two events (fdgs_forward_out.split_colour) and the run-ahead guesses (sizes of the thread's previous forward calls per
  * (device, W, H, P)).  Consequence: any number of host threads may call concurrently (each with its own stream), and one
  * thread may drive several devices (hipSetDevice before the call); within ONE thread a forward call has returned before the
@@ -51,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 310 /* 0.3.0.  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+#define FDGS_VERSION 400 /* 0.4.0.  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
                             (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
                             FDGS_VERSION: a binding built against another revision of this header is turned away instead of
                             having the library read past the end of a shorter struct. */
@@ -150,6 +151,17 @@ typedef struct fdgs_forward_out
 	                         (to fp32 rounding: the blend kernels pair the list entries differently); num_rendered, the
 	                         lists and n_contrib (a list position) are not: a quarter fewer instances at C3.  The backward takes
 	                         whatever lists the forward left */
+	int32_t lazy;         /* 0: the call returns num_rendered (it waits for the tile scan, as the reference does at
+	                         rasterizer_impl.cu:302, and starts over from the scatter pass when its run-ahead guess was too small).
+	                         1: when the call can run ahead (the thread has rendered this (device, W, H, P) before, no debug mode) it
+	                         enqueues the whole forward with generous buffers -- 1.5 x the largest num_rendered / longest list of the
+	                         thread's last four reports -- and returns WITHOUT waiting: *num_rendered = -1 ("not known yet"; the backward
+	                         accepts -1: the tile ranges carry everything the kernels need) and the host never blocks on the device.  If
+	                         the lists turn out not to fit, scatter and sort leave everything alone ON THE DEVICE and the forward's outputs
+	                         are INVALID (background only): fdgs_forward_lazy_status reports it, and the caller renders that view again
+	                         with lazy = 0 BEFORE anything irreversible depends on it (fdgs.pipeline.StepPipeline: before the optimizer
+	                         step of the views' batch).  Where it cannot run ahead (first call for a configuration, debug mode,
+	                         fdgs_set_run_ahead(0)) the call behaves as with 0 and returns num_rendered >= 0. */
 } fdgs_forward_out;
 
 /* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output
@@ -167,7 +179,7 @@ typedef struct fdgs_backward_in
 	const void* geom_buffer;     /* the three scratch buffers of the forward call  */
 	const void* binning_buffer;
 	const void* image_buffer;
-	int32_t num_rendered;        /* R returned by forward                          */
+	int32_t num_rendered;        /* R returned by forward (-1 from a lazy forward: fine) */
 } fdgs_backward_in;
 
 /* Gradients; every non-NULL array is fully written by the call (no pre-zeroing
@@ -221,6 +233,14 @@ typedef struct fdgs_backward_out
 int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
                            fdgs_alloc_fn alloc, void* alloc_user, void* stream,
                            int32_t* num_rendered);
+
+/* The lazy forwards (fdgs_forward_out.lazy) of the CALLING THREAD on the current device, since the previous call of this function:
+ * *pending = how many have not reported yet (always 0 with wait != 0: the call then blocks until the tile scan of the most recent one
+ * has run -- `stream`, optional, is polled meanwhile so that a failed launch ends the wait); *failed = how many turned out not to fit
+ * their buffers: the outputs of those forwards are invalid and must be rendered again with lazy = 0; num_rendered[0 .. *n_out) = the
+ * num_rendered of the reported ones, oldest first (at most max_out, at most 64).  Every pointer may be NULL. */
+int fdgs_forward_lazy_status(int32_t wait, void* stream, int32_t* pending, int32_t* failed,
+                             int32_t* num_rendered, int32_t max_out, int32_t* n_out);
 
 /* 1 (default): the forward enqueues scatter / sort / blend before num_rendered is back, with a binning buffer sized from the
  * calling thread's previous call; 0: it always waits and asks the allocator for exactly fdgs_binning_bytes(num_rendered)

@@ -535,3 +535,37 @@ def test_spatial_sort_renders_the_same_images(gpu_device):
         # Adam's first step moves a parameter by ~lr whatever the gradient's size: where a gradient is float-atomics noise around
         # zero its sign may differ between two runs (2 lr)
         assert ((a - b).abs() > 2e-3).float().mean().item() <= 2e-3, n
+
+
+def test_step_pipeline_lazy_equals_waiting_and_redoes_an_overflowing_step(gpu_device):
+    """StepPipeline(lazy=True) -- no forward of the step waits for num_rendered, one look at the reports before the last view's
+    backward -- takes the same optimizer steps as lazy=False; a step whose views outgrow the run-ahead buffers is redone through the
+    waiting path before anything of the optimizer step has been enqueued (lazy_redone counts it) and still equals the waiting run."""
+    from fdgs import train_host
+    from fdgs.pipeline import StepPipeline
+    cfg = synth.SceneConfig("lzp", 6007, 208, 160, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=4)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    pipe = train_host.PipelineFlags()
+    B = 3
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / B * scene["time_duration"]) for b in range(B)]
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(gpu_device) for _ in range(B)]
+    runs = {}
+    for lazy in (False, True):
+        m = train_host.GaussianParams(scene, gpu_device)
+        sp = StepPipeline(m, train_host.make_optimizer(m), world_size=1, lambda_dssim=0.2, lazy=lazy)
+        losses, Rs = [], []
+        # steps 0-1 at scaling_modifier 1, step 2 at 2.6 (2.7 x the instances, 2.4 x the longest list: beyond the 1.5 x + 64 the sort
+        # instances of a lazy forward are launched for), step 3 at 2.6 again (the guess has learnt it)
+        for mod in (1.0, 1.0, 2.6, 2.6):
+            results, ls = sp.step(cams, gts, pipe, bg, scaling_modifier=mod)
+            losses += [float(l) for l in ls]
+            Rs += [r["num_rendered"] for r in results]
+        torch.cuda.synchronize()
+        runs[lazy] = (m.flat.detach().clone(), losses, Rs, sp.lazy_redone)
+    assert runs[False][3] == 0 and runs[True][3] == 1, (runs[False][3], runs[True][3])
+    assert runs[True][2] == runs[False][2] and min(runs[True][2]) > 0, (runs[True][2], runs[False][2])
+    np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=1e-5, atol=1e-6)
+    perr = (runs[True][0] - runs[False][0]).abs()
+    assert (perr > 2e-3).float().mean().item() <= 2e-3 and perr.max().item() <= 0.25   # (Adam on float-atomics noise: see above)

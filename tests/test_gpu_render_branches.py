@@ -46,17 +46,45 @@ CASES = {
 }
 
 
+def _conjugated(model):
+    """The same model with the spatial rotation inverted (quaternion conjugate)."""
+    import copy
+    other = copy.copy(model)
+    with torch.no_grad():
+        other._rotation = torch.nn.Parameter(model._rotation.detach() * torch.tensor([1.0, -1.0, -1.0, -1.0], device=model._rotation.device))
+    return other
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_python_covariance_matches_kernel_covariance(name, gpu_device):
+    """render() with pipe.compute_cov3D_python against render() with the in-kernel covariance.
+
+    rot_4d: the model's get_current_covariance_and_mean_offset (L L^T with L = R4 S, gaussian_model.py:34-47) is the kernel's
+    conditional covariance (forward.cu:279-352): same image.
+    3D / 4D without rot_4d: the reference's Python covariance is (S R)^T (S R) = R^T S^2 R (gaussian_model.py:28-32 with
+    general_utils.py:103-111 ``L = L @ R``) while its kernel computes R S^2 R^T (forward.cu:242-276: glm::mat3's constructor is
+    column-major, so its R is the transpose of build_rotation's): the reference's two paths render DIFFERENT images -- the Python
+    one rotates every splat with the inverse quaternion.  The branch is therefore checked against the kernel path of the model
+    with conjugated rotations, which must give the Python path's image."""
     from fdgs.gaussian_renderer import render
     cfg, mod, pv = CASES[name]
-    scene, model, cam = _setup(cfg, gpu_device, prefilter_var=pv)
+    from fdgs import train_host
+    scene = synth.make_scene(cfg, seed=6, bg=(0.1, 0.3, 0.2))
+    if cfg.gaussian_dim == 4 and not cfg.rot_4d:
+        scene["scales_t"] = scene["scales_t"] * 0.03   # (a variance here, forward.cu:431-437) small enough for the 0.05 mask to remove some
+    model = train_host.ReferenceStyleModel(scene, gpu_device)
+    model.prefilter_var = pv
+    cam = train_host.SyntheticCamera(scene, gpu_device)
     bg = scene["bg"].to(gpu_device)
     P = cfg.P
-    a = render(cam, model, _Pipe(), bg, scaling_modifier=mod)
+    kernel_model = model if cfg.rot_4d else _conjugated(model)
+    a = render(cam, kernel_model, _Pipe(), bg, scaling_modifier=mod)
     pp = _Pipe()
     pp.compute_cov3D_python = True
     b = render(cam, model, pp, bg, scaling_modifier=mod)
+    if not cfg.rot_4d:
+        c = render(cam, model, _Pipe(), bg, scaling_modifier=mod)
+        assert float((c["render"] - b["render"]).abs().max()) > 1e-2, "un-conjugated kernel path equals the Python path: the docstring is wrong"
     # same keys / shapes; radii scattered back to all P Gaussians through the marginal_t mask (gaussian_renderer/__init__.py:178-182)
     assert set(a) == set(b)
     assert b["radii"].shape == (P,) and b["visibility_filter"].shape == (P,) and b["viewspace_points"].shape == (P, 3)
@@ -64,41 +92,43 @@ def test_python_covariance_matches_kernel_covariance(name, gpu_device):
     if cfg.gaussian_dim == 4:
         m = model.get_marginal_t(cam.timestamp)[:, 0].detach().cpu().numpy()
         assert (rb[m <= 0.05] == 0).all(), "a Gaussian the marginal_t mask removed has a radius"
-        assert (m > 0.05).sum() < P, "the mask removed nothing: the case does not test the scatter-back"
+        assert 0 < (m > 0.05).sum() < P, "the mask removed nothing (or everything): the case does not test the scatter-back"
     # the two covariances differ in the last bits (torch.bmm vs the kernel's GLM-ordered products): a radius = ceil(3 sigma) may
     # flip for a handful of Gaussians, a marginal within rounding of 0.05 may be culled on one side only
     flips = int((ra != rb).sum())
     assert flips <= max(2, P // 1000), "%s: %d radii differ between the two covariance paths" % (name, flips)
-    assert np.abs(ra.astype(np.int64) - rb).max() <= 1 or flips <= 2
     worst = {}
     for k in ("render", "depth", "alpha"):
+        tol = 1e-5 * max(1.0, float(a[k].abs().max()))
         d = (a[k] - b[k]).abs()
-        frac = float((d > 1e-5).float().mean())
+        frac = float((d > tol).float().mean())
         worst[k] = (float(d.max()), frac)
-        # <= 1e-5 everywhere except where an alpha >= 1/255 / T >= 1e-4 decision fell the other way (a 1e-6 relative change of
-        # the conic moves ~1e-4 of the pixels across a threshold; each such pixel moves by <= 1/255 of a colour)
-        assert frac <= 2e-3 and worst[k][0] <= 2e-2 * max(1.0, float(a[k].abs().max())), "%s: %s differs: max %g, %g of the pixels beyond 1e-5" % (
-            name, k, worst[k][0], frac)
-    print(name, "radii flips", flips, {k: "max %.1e, frac>1e-5 %.1e" % v for k, v in worst.items()})
+        # <= 1e-5 (of the output's scale) everywhere except where an alpha >= 1/255 / T >= 1e-4 decision fell the other way (a 1e-6
+        # relative change of the conic moves ~1e-4 of the pixels across a threshold; each such pixel moves by <= 1/255 of a colour)
+        assert frac <= 2e-3 and worst[k][0] <= 2e3 * tol, "%s: %s differs: max %g, %g of the pixels beyond %g" % (name, k, worst[k][0], frac, tol)
+    print(name, "radii flips", flips, {k: "max %.1e, frac beyond 1e-5 of scale %.1e" % v for k, v in worst.items()})
     # gradients flow through the Python covariance (autograd) into every parameter and the screen-space means
     up = torch.from_numpy(np.random.default_rng(0).standard_normal((3, scene["H"], scene["W"])).astype(np.float32)).to(gpu_device) * 1e-2
     params = ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"] + (["_t", "_scaling_t"] if cfg.gaussian_dim == 4 else []) + (
         ["_rotation_r"] if cfg.rot_4d else [])
     grads = {}
-    for tag, pkg in (("kernel", a), ("python", b)):
+    for tag, pkg, mdl in (("kernel", a, kernel_model), ("python", b, model)):
         for n in params:
-            getattr(model, n).grad = None
+            getattr(mdl, n).grad = None
         (pkg["render"] * up).sum().backward()
-        grads[tag] = {n: (getattr(model, n).grad.detach().clone() if getattr(model, n).grad is not None else None) for n in params}
+        grads[tag] = {n: (getattr(mdl, n).grad.detach().clone() if getattr(mdl, n).grad is not None else None) for n in params}
         assert pkg["viewspace_points"].grad is not None and torch.isfinite(pkg["viewspace_points"].grad).all()
     for n in params:
         g = grads["python"][n]
         assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, "python path: no gradient reached %s" % n
     if cfg.gaussian_dim == 3:
         # 3D: the in-kernel covariance backward is the analytic one (computeCov3D, backward.cu:619-700; no quirk on this path), so
-        # autograd through the Python covariance must agree with it
+        # autograd through the Python covariance must agree with it (rotation: through the conjugation)
+        conj = torch.tensor([1.0, -1.0, -1.0, -1.0], device=gpu_device)
         for n in params:
             ga, gb = grads["kernel"][n], grads["python"][n]
+            if n == "_rotation":
+                ga = ga * conj
             scale = max(1.0, float(ga.abs().max()))
             d = (ga - gb).abs()
             assert float((d > 1e-4 * scale).float().mean()) <= 2e-3 and float(d.max()) <= 5e-2 * scale, "%s: d/d%s differs between the paths: %g (scale %g)" % (
