@@ -21,7 +21,7 @@ from . import _capi
 from .fused import raw_backward, raw_forward, raw_preprocess_batch, raw_settings
 from .gaussian_renderer import diff_gaussian_rasterization as _dgr
 from .loss import l1_ssim_grad, l1_ssim_loss
-from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stage_begin
+from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stage_begin, timed_wait
 
 
 class StepPipeline:
@@ -53,6 +53,9 @@ class StepPipeline:
         # Several ranks: off (the decision to start over would have to be collective).
         self.lazy = bool(lazy)
         self.lazy_redone = 0
+        # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
+        # is bracketed by two timing events appended to it (train_host.timed_wait): the exchange time nothing overlapped
+        self.exchange_pairs = None
         self.split_colour = bool(split_colour)   # fdgs_forward_out.split_colour for the views' forwards (A/B; off: see DESIGN)
         # View batching (opt-in, B > 1): the SH coefficients -- 12 M bytes per Gaussian, most of what preprocess and SH backward
         # read -- are the same for every view of the step.  ``batch_views``: the views' geometry still runs per view, but their SH
@@ -228,16 +231,17 @@ class StepPipeline:
                 geo = dist.all_reduce(m.flat_grad[:feat], op=dist.ReduceOp.SUM, async_op=True)   # 17 floats per Gaussian
                 self.opt.step_count += 1
                 for work in sh_gather:
-                    work.wait()
+                    timed_wait(work, self.exchange_pairs)
                 stages = self._gathered.view(-1, m.P, 8)   # [B x world] views: view-major, rank-minor, the same on every rank
                 ok = self.opt.step_sh_staged(stages, rs, _dgr.analytic_sh_gradients())
                 if not ok:   # layout the fused kernel does not take: every rank builds the same summed dL_dsh from all the stages
                     _capi.sh_flush(stages, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim, rs.force_sh_3d,
                                    _dgr.analytic_sh_gradients())
-                geo.wait()
+                timed_wait(geo, self.exchange_pairs)
                 self.opt.step_range(0, feat if ok else m.flat.numel())
             else:
-                allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None)
+                allreduce_and_step(m, self.opt, self.world, chunks=4, average=False, sh_handle=sh_handle[0] if sh_handle else None,
+                                   wait_pairs=self.exchange_pairs)
 
     def _after_sh(self, rs, fuse, gather, defer_sh, sh_handle, sh_gather, sh_stepped):
         """What starts as soon as the SH stages of the step are complete (stream B is current): the fused SH update on the idle F

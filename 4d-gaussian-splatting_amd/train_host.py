@@ -475,8 +475,22 @@ def gather_view_stage_begin(stage: torch.Tensor, out: torch.Tensor):
     return dist.all_reduce(out, op=dist.ReduceOp.SUM, async_op=True)
 
 
+def timed_wait(work, pairs=None):
+    """``work.wait()`` (the current stream waits for the collective); with ``pairs`` a list: bracketed by two timing events on the
+    current stream, appended as (before, after) -- their elapsed time is what the stream stood still for this collective, i.e. the
+    part of the exchange that nothing overlapped."""
+    if pairs is None:
+        work.wait()
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    work.wait()
+    b.record()
+    pairs.append((a, b))
+
+
 def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: int, chunks: int = 4, average: bool = False,
-                       sh_handle=None) -> None:
+                       sh_handle=None, wait_pairs=None) -> None:
     """Gradient all-reduce + Adam with the two overlapped: the bucket is cut into pieces, all all-reduces are issued
     at once (they run back to back on the collective stream) and a piece is updated as soon as ITS all-reduce has
     finished, while the next one is still on the wire.  ``sh_handle``: the SH part is already in flight
@@ -497,7 +511,7 @@ def allreduce_and_step(model: GaussianParams, optimizer: FlatAdam, world_size: i
         works = list(sh_handle) + works     # the SH pieces were issued first and finish first
     optimizer.step_count += 1
     for w, b, e in works:
-        w.wait()
+        timed_wait(w, wait_pairs if model.flat.is_cuda else None)
         if average:
             model.flat_grad[b:e].mul_(1.0 / world_size)
         optimizer.step_range(b, e)

@@ -373,6 +373,18 @@ def main():
         opt.step()
         return [pkg]
 
+    # The targets are noise, so hundreds of Adam steps at the reference's learning rates drive the model away from the workload the
+    # metric is quoted on (opacities and scales shrink: a third of the instances are left after 400 steps).  Every timed leg therefore
+    # starts from the SAME state: parameters, Adam moments and step count are put back (three device copies, INSIDE the timed region
+    # where one is timed: extra work, nothing skipped) after the warm-up and before every repetition of the --steps steps.
+    snap = (model.flat.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
+
+    def restore():
+        model.flat.data.copy_(snap[0])
+        opt.exp_avg.copy_(snap[1])
+        opt.exp_avg_sq.copy_(snap[2])
+        opt.step_count = snap[3]
+
     # warm-up: --warmup steps, and on until --min-warmup-ms of wall time have passed (the driver's --warmup 5 is 15 ms of C3 steps;
     # the shader clock takes ~100 ms of load to settle)
     torch.cuda.synchronize(dev)
@@ -426,7 +438,8 @@ def main():
         dist.all_reduce(t_reps, op=dist.ReduceOp.MAX)
         reps = int(t_reps.item())
     steps_timed = reps * args.steps
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps_timed + 1)]
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps_timed)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps_timed)]
     # shader clock actually sustained during the timed steps: a one-wave sampler on its own stream spans ~80 % of the region
     # (its length estimated from two more untimed steps)
     est_ms = est_step_ms * steps_timed
@@ -441,14 +454,18 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    if use_pipeline and world > 1:
+        steppipe.exchange_pairs = []   # stream B's waits for the collectives, bracketed by timing events
     barrier(world)
     t0 = time.perf_counter()
-    marks[0].record()
     if clock is not None:
         clock.start(min(max(0.8 * est_ms, 1.0), 1500.0))
     for i in range(steps_timed):
+        if i % args.steps == 0:
+            restore()   # inside the timed region: ~0.25 ms of copies per --steps steps (not part of any step's own event pair)
+        starts[i].record()
         pkg = step()
-        marks[i + 1].record()
+        ends[i].record()
     torch.cuda.synchronize(dev)
     barrier(world)
     dt = time.perf_counter() - t0
@@ -460,8 +477,24 @@ def main():
     except Exception:
         shader_ghz = None
     prof_dom = _capi.profile_read()[dom]
+    # N > 1: every rank's own wall time per step and the exchange time nothing overlapped (the sum of stream B's waits for a
+    # collective per step, train_host.timed_wait), so that a scaling run explains itself
+    per_rank = None
+    if world > 1:
+        import torch.distributed as dist
+        exposed = None
+        if use_pipeline and steppipe.exchange_pairs:
+            exposed = sum(a.elapsed_time(b) for a, b in steppipe.exchange_pairs) / steps_timed
+            steppipe.exchange_pairs = None
+        allr = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        allr[rank, 0], allr[rank, 1] = dt / steps_timed * 1e3, (-1.0 if exposed is None else exposed)
+        dist.all_reduce(allr, op=dist.ReduceOp.SUM)   # (a gather spelt as a sum: works on every backend the debug runs use)
+        per_rank = {"ms_per_step": [round(float(t[0]), 4) for t in allr],
+                    "exchange_exposed_ms": None if exposed is None else [round(float(t[1]), 4) for t in allr],
+                    "what": "per rank: wall time per step of the timed region; exchange_exposed_ms = per step, the time the backward stream stood still "
+                            "waiting for a collective (stage all-gathers / gradient all-reduces): the part of the exchange nothing overlapped"}
     dt = max_over_ranks(dt, world, dev)
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps_timed))
+    step_ms = sorted(starts[i].elapsed_time(ends[i]) for i in range(steps_timed))
     r_last = [r["num_rendered"] for r in pkg if isinstance(r, dict) and r.get("num_rendered", -1) >= 0]
     R_timed = (sum(r_last) / len(r_last)) if r_last else (sum(_R_LOG) / max(len(_R_LOG), 1))
     lazy_redone = steppipe.lazy_redone if use_pipeline else None
@@ -492,6 +525,7 @@ def main():
 
     fwd_lazy_failed = 0
 
+    restore()
     with torch.no_grad():
         for _ in range(20):   # right behind the timed steps (the shader clock is up); a few more calls settle the allocator on this stream
             forward_only(cam)
@@ -553,6 +587,7 @@ def main():
     if use_pipeline and args.reflists_steps > 0 and not args.no_tile_cull:
         rp = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
                           gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy)
+        restore()
         for _ in range(3):
             rp.step(cams, gts, pipe, bg)
         torch.cuda.synchronize(dev)
@@ -571,6 +606,7 @@ def main():
     # the same step with the model stored in Morton order (a memory-layout choice of the trainer, no effect on the arithmetic)
     spatial = None
     if use_pipeline and args.spatial_order_steps > 0:
+        restore()
         train_host.spatial_sort(model, opt)
         for _ in range(3):
             step()
@@ -702,6 +738,8 @@ def main():
         "roofline": roofline,
     }
     out["rccl_ranks"] = world
+    if per_rank:
+        out["per_rank"] = per_rank
     out["backend"] = backend if backend else "none (single process)"
     if reflists:
         out["value_reference_lists"] = reflists["images_s"]

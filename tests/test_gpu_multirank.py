@@ -27,7 +27,7 @@ def _free_port():
 def test_bench_two_ranks_share_one_gpu(views, dense, gpu_device):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--min-warmup-ms", "0", "--min-timed-ms", "0",
            "--workload", "C2", "--views-per-step", str(views), "--cpu-samples", "0"] + (["--dense-sh-exchange"] if dense else [])
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -46,7 +46,7 @@ def test_bench_launches_its_own_ranks(gpu_device):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C2",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup-ms", "0", "--min-timed-ms", "0", "--workload", "C2",
            "--cpu-samples", "0", "--host-cost-steps", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -64,14 +64,14 @@ def test_bench_refuses_more_ranks_than_gpus(gpu_device):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDGS_BENCH_DEBUG_SHARE_GPU"):
         env.pop(k, None)
     n = torch.cuda.device_count() + 1
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--min-warmup-ms", "0", "--min-timed-ms", "0"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "GPU(s) visible" in (out.stderr + out.stdout)
 
 
 def _run_bench(nproc, views, extra=()):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--workload", "C2",
+    common = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--min-warmup-ms", "0", "--min-timed-ms", "0", "--workload", "C2",
               "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0", "--dropin-steps", "0", "--spatial-order-steps", "0"] + list(extra)
     if nproc == 1:
         cmd = [sys.executable] + common
@@ -93,3 +93,54 @@ def test_two_ranks_make_the_same_update_as_one(dense, gpu_device):
     assert two["replicas_identical"] is True and two["config"]["global_batch"] == one["config"]["global_batch"] == 4
     (s1, a1), (s2, a2) = one["param_digest"], two["param_digest"]
     assert abs(a1 - a2) <= 1e-5 * a1 and abs(s1 - s2) <= 1e-5 * a1, (one["param_digest"], two["param_digest"])
+
+
+def _run_bench_rccl(nproc, views, extra=()):
+    """bench.py over RCCL: one rank per GPU (no debug sharing), launched as the driver launches the N > 1 bench."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDGS_BENCH_DEBUG_SHARE_GPU"):
+        env.pop(k, None)
+    common = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--min-warmup-ms", "0", "--min-timed-ms", "0",
+              "--workload", "C2", "--views-per-step", str(views), "--cpu-samples", "0", "--host-cost-steps", "0", "--dropin-steps", "0",
+              "--spatial-order-steps", "0", "--reflists-steps", "0"] + list(extra)
+    if nproc == 1:
+        cmd = [sys.executable] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + common
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the exchange over RCCL / xGMI (the 1-GPU boxes run the gloo variant above)")
+@pytest.mark.parametrize("dense", [False, True])
+def test_rccl_two_gpus_make_the_same_update_as_one(dense, gpu_device):
+    """The moment two GPUs are visible: 2 ranks x 2 views over **nccl (RCCL)** -- stage all-gather and dense all-reduce -- against
+    1 rank x 4 views: replicas bit-identical, the same update (float atomics aside), per-rank timings reported."""
+    one = _run_bench_rccl(1, 4)
+    two = _run_bench_rccl(2, 2, ["--dense-sh-exchange"] if dense else [])
+    assert two["backend"] == "nccl" and two["rccl_ranks"] == 2 and two["n_gpus"] == 2
+    assert two["replicas_identical"] is True and two["config"]["global_batch"] == one["config"]["global_batch"] == 4
+    (s1, a1), (s2, a2) = one["param_digest"], two["param_digest"]
+    assert abs(a1 - a2) <= 1e-5 * a1 and abs(s1 - s2) <= 1e-5 * a1, (one["param_digest"], two["param_digest"])
+    assert len(two["per_rank"]["ms_per_step"]) == 2 and two["per_rank"]["exchange_exposed_ms"] is not None
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs")
+def test_rccl_bench_launches_itself_on_two_gpus(gpu_device):
+    """`python bench.py --gpus 2` as the driver's N = 1 command line would be extended: self-launch, one rank per GPU, RCCL."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDGS_BENCH_DEBUG_SHARE_GPU"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "C2", "--cpu-samples", "0",
+                          "--host-cost-steps", "0", "--dropin-steps", "0", "--spatial-order-steps", "0", "--reflists-steps", "0", "--min-timed-ms", "100"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["backend"] == "nccl" and d["replicas_identical"] is True and d["scaling"] == "weak"

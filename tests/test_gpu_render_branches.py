@@ -129,6 +129,10 @@ def test_python_covariance_matches_kernel_covariance(name, gpu_device):
             ga, gb = grads["kernel"][n], grads["python"][n]
             if n == "_rotation":
                 ga = ga * conj
+            if n == "_scaling":
+                # the kernel returns dL/d(mod * scale) as dL/dscale (backward.cu:638-668: S is built from mod * scale, dL_dscale =
+                # dot(Rt, dL_dMt) without the modifier) -- the reference's own gradient is short of the factor scale_modifier
+                ga = ga * mod
             scale = max(1.0, float(ga.abs().max()))
             d = (ga - gb).abs()
             assert float((d > 1e-4 * scale).float().mean()) <= 2e-3 and float(d.max()) <= 5e-2 * scale, "%s: d/d%s differs between the paths: %g (scale %g)" % (
