@@ -20,6 +20,90 @@ def _select(mask, *tensors):
     return tuple(None if t is None else t[mask] for t in tensors)
 
 
+# Options of the fast path below (process-wide).  tile_cull: fdgs_forward_out.tile_cull -- shorter tile lists, same pixels and
+# gradients (off: point_list / ranges / n_contrib are the reference's, bit for bit).
+# fast_path: False sends every model through the reference's own sequence (getters -> activations in PyTorch -> rasterizer).
+render_options = {"tile_cull": False, "fast_path": True}
+
+_RAW_ATTRS = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+
+
+class _RasterizeModel(torch.autograd.Function):
+    """The rasterizer on a reference-style model's RAW parameters (fdgs_scene.raw_params: activations inside the kernels).
+    With an ``fdgs.optim.Adam`` that owns the parameters (``opt``), the backward writes the parameter gradients straight into the
+    optimizer's flat gradient bucket behind ``p.grad`` and returns nothing for them; otherwise it returns them to autograd."""
+
+    @staticmethod
+    def forward(ctx, means2D, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, rs, opt, tile_cull, lazy):
+        from ..fused import raw_forward
+        (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
+            rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, tile_cull=tile_cull, lazy=lazy)
+        ctx.rs, ctx.R, ctx.prefilter_var, ctx.opt = rs, R, prefilter_var, opt
+        ctx.save_for_backward(xyz, out_means3D, scaling, rotation, radii, feats, opacity, ts, scaling_t, rotation_r, geom, binb, img)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None: colour-only backward
+        if opt is not None:
+            opt.note_forward(R < 0)
+        return color, radii, depth, 1 - T, flow
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha, g_flow):
+        from ..fused import raw_backward
+        from .diff_gaussian_rasterization import _is_given
+        rs, opt = ctx.rs, ctx.opt
+        (xyz, out_means3D, scaling, rotation, radii, feats, opacity, ts, scaling_t, rotation_r, geom, binb, img) = ctx.saved_tensors
+        if g_color is None and g_depth is None and g_alpha is None and g_flow is None:
+            g_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=xyz.device)
+        sunk = opt is not None and opt.is_homed() and opt.features().data_ptr() == feats.data_ptr()
+        if sunk:
+            sink, accumulate, gacc, stage = opt.backward_begin(rs)
+            grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, ctx.prefilter_var,
+                                 geom, ctx.R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=gacc, sh_stage=stage)
+            return (grads[0],) + (None,) * 13
+        (d_means2D, _dc, d_opacity, d_means3D, _dcov, d_sh, _df, d_ts, d_scales, d_scales_t, d_rot, d_rot_r) = raw_backward(
+            rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, ctx.prefilter_var, geom, ctx.R, binb, img,
+            g_color, g_depth, g_alpha, g_flow, None, False)
+
+        def shaped(given, g):
+            return g.reshape(given.shape) if _is_given(given) else None
+
+        return (d_means2D, d_means3D, shaped(feats, d_sh), shaped(opacity, d_opacity), shaped(ts, d_ts), shaped(scaling, d_scales),
+                shaped(scaling_t, d_scales_t), shaped(rotation, d_rot), shaped(rotation_r, d_rot_r), None, None, None, None, None)
+
+
+def _fast_path(viewpoint_camera, pc, pipe, raster_settings, means2D):
+    """A reference-style model (raw ``_scaling`` / ``_rotation`` / ``_opacity`` / ``_features_dc`` / ``_features_rest`` ... attributes,
+    scene/gaussian_model.py:70-80) on the default pipeline: the kernels take the RAW parameters and apply the activations of
+    :179-209 themselves (no exp / sigmoid / normalize kernels forward and backward); with ``fdgs.optim.Adam`` as ``pc.optimizer``
+    also no ``torch.cat`` of the SH coefficients and no gradient accumulation pass (see fdgs/optim.py).  None: not applicable."""
+    if pipe.compute_cov3D_python or pipe.convert_SHs_python or pipe.debug or not render_options["fast_path"]:
+        return None
+    if not all(isinstance(getattr(pc, a, None), torch.Tensor) for a in _RAW_ATTRS):
+        return None
+    xyz = pc._xyz
+    if not xyz.is_cuda or xyz.dtype != torch.float32 or pc._features_dc.dim() != 3:
+        return None
+    is_4d = pc.gaussian_dim == 4
+    if is_4d and not (isinstance(getattr(pc, "_t", None), torch.Tensor) and isinstance(getattr(pc, "_scaling_t", None), torch.Tensor)):
+        return None
+    if is_4d and pc.rot_4d and not isinstance(getattr(pc, "_rotation_r", None), torch.Tensor):
+        return None
+    from ..optim import Adam as _FdgsAdam
+    e = torch.Tensor([])
+    opt = getattr(pc, "optimizer", None)
+    prefilter_var = pc.prefilter_var if (is_4d and pc.prefilter_var > 0.0) else -1.0
+    if isinstance(opt, _FdgsAdam) and torch.is_grad_enabled() and opt.ensure_homed() and opt._homed["xyz"][0] is xyz:
+        tensors = opt.model_tensors(pc.gaussian_dim, pc.rot_4d)
+        lazy = opt.lazy_forward
+    else:
+        opt, lazy = None, False
+        tensors = (xyz, pc.get_features, pc._opacity, pc._t if is_4d else e, pc._scaling, pc._scaling_t if is_4d else e, pc._rotation,
+                   pc._rotation_r if (is_4d and pc.rot_4d) else e)
+    (x, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r) = tensors
+    return _RasterizeModel.apply(means2D, x, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var,
+                                 raster_settings, opt, bool(render_options["tile_cull"]), lazy)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene seen by ``viewpoint_camera``.  ``bg_color`` must live on the model's device."""
     xyz = pc.get_xyz
@@ -53,6 +137,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         debug=pipe.debug,
     )
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    fast = _fast_path(viewpoint_camera, pc, pipe, raster_settings, screenspace_points) if override_color is None else None
+    if fast is not None:
+        rendered_image, radii, depth, alpha, flow = fast
+        return _finish(viewpoint_camera, pc, pipe, screenspace_points, rendered_image, radii, depth, alpha, flow, None)
 
     means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
     scales = scales_t = rotations = rotations_r = ts = cov3D_precomp = None
@@ -120,6 +209,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         opacities=opacity, ts=ts, scales=scales, scales_t=scales_t, rotations=rotations, rotations_r=rotations_r,
         cov3D_precomp=cov3D_precomp, prefilter_var=prefilter_var)
 
+    return _finish(viewpoint_camera, pc, pipe, screenspace_points, rendered_image, radii, depth, alpha, flow, mask)
+
+
+def _finish(viewpoint_camera, pc, pipe, screenspace_points, rendered_image, radii, depth, alpha, flow, mask):
+    """Environment map behind the Gaussians, radii scattered back through the marginal_t mask, the result dict
+    (gaussian_renderer/__init__.py:165-194)."""
     if pipe.env_map_res:
         # composite an environment map behind the Gaussians (sphere of radius 60)
         assert pc.env_map is not None

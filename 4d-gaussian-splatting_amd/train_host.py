@@ -146,7 +146,9 @@ class ReferenceStyleModel:
     PyTorch activations in the getters (scene/gaussian_model.py:179-219), ``torch.optim.Adam(lr=0, eps=1e-15)`` over one param
     group per tensor (:331-357).  bench.py's drop-in leg times ``render()`` + autograd + this optimizer on it; nothing else uses it."""
 
-    def __init__(self, scene: Dict[str, object], device):
+    def __init__(self, scene: Dict[str, object], device, optimizer: str = "torch"):
+        """``optimizer``: "torch" = ``torch.optim.Adam`` as the reference builds it (scene/gaussian_model.py:353); "fdgs" =
+        ``fdgs.optim.Adam`` over the same param groups (the one-line swap INTEGRATION.md describes)."""
         M = int(scene["M"])
         mk = lambda t: torch.nn.Parameter(t.to(device).float().contiguous().requires_grad_(True))  # noqa: E731
         self._xyz = mk(scene["means3D"])
@@ -172,7 +174,68 @@ class ReferenceStyleModel:
             groups += [dict(params=[self._t], lr=1.6e-4, name="t"), dict(params=[self._scaling_t], lr=5e-3, name="scaling_t")]
             if self.rot_4d:
                 groups.append(dict(params=[self._rotation_r], lr=1e-3, name="rotation_r"))
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        if optimizer == "fdgs":
+            from .optim import Adam as FdgsAdam
+            self.optimizer = FdgsAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    # the attribute every parameter group's tensor lives under (scene/gaussian_model.py:411-425, 456-470)
+    _ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+             "rotation": "_rotation", "t": "_t", "scaling_t": "_scaling_t", "rotation_r": "_rotation_r"}
+
+    def _adopt(self, tensors: Dict[str, torch.Tensor]):
+        for name, t in tensors.items():
+            setattr(self, self._ATTR[name], t)
+
+    # ---- how the reference's densification edits the optimizer (scene/gaussian_model.py:376-452): restated so that the tests can
+    # put ANY optimizer through the same manipulations: state dicts moved from the old Parameter to the new one, moments gathered /
+    # extended with zeros, ``group["params"][0]`` replaced by a fresh nn.Parameter ----
+    def replace_tensor_to_optimizer(self, tensor: torch.Tensor, name: str):
+        """:376-389 (reset_opacity): new values, zeroed moments."""
+        for group in self.optimizer.param_groups:
+            if group["name"] != name:
+                continue
+            old = group["params"][0]
+            st = self.optimizer.state.get(old, None)
+            st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(tensor), torch.zeros_like(tensor)
+            del self.optimizer.state[old]
+            group["params"][0] = torch.nn.Parameter(tensor.requires_grad_(True))
+            self.optimizer.state[group["params"][0]] = st
+            self._adopt({name: group["params"][0]})
+
+    def prune_points(self, mask: torch.Tensor):
+        """:391-429 (_prune_optimizer + prune_points): rows where ``mask`` is True go."""
+        keep = ~mask
+        out = {}
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            st = self.optimizer.state.get(old, None)
+            if st is not None:
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][keep], st["exp_avg_sq"][keep]
+                del self.optimizer.state[old]
+            group["params"][0] = torch.nn.Parameter(old[keep].requires_grad_(True))
+            if st is not None:
+                self.optimizer.state[group["params"][0]] = st
+            out[group["name"]] = group["params"][0]
+        self._adopt(out)
+
+    def densification_postfix(self, new: Dict[str, torch.Tensor]):
+        """:431-470 (cat_tensors_to_optimizer + densification_postfix): rows appended, their moments zero."""
+        out = {}
+        for group in self.optimizer.param_groups:
+            ext = new[group["name"]]
+            old = group["params"][0]
+            st = self.optimizer.state.get(old, None)
+            if st is not None:
+                st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0)
+                st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+                del self.optimizer.state[old]
+            group["params"][0] = torch.nn.Parameter(torch.cat((old, ext), dim=0).requires_grad_(True))
+            if st is not None:
+                self.optimizer.state[group["params"][0]] = st
+            out[group["name"]] = group["params"][0]
+        self._adopt(out)
 
     get_xyz = property(lambda s: s._xyz)
     get_t = property(lambda s: s._t)

@@ -262,8 +262,44 @@ def dropin_leg(args, scene, cams, gts, pipe, bg, dev, B):
 
     ms_fwd, ms_fb, ms_loss, ms_opt = timed(fwd, 8), timed(fwd_bwd, 4), timed(torch_loss, 4), timed(optim, 3)
     rm.optimizer.zero_grad(set_to_none=True)
+    del rm
+
+    # The reference's loop with the three swaps INTEGRATION.md describes: this package's render(), fdgs.loss.fused_l1_ssim for the
+    # loss expression, fdgs.optim.Adam for torch.optim.Adam in training_setup -- model class, getters, densification code, loop
+    # structure (autograd, one view after the other, optimizer.step / zero_grad) untouched.
+    import fdgs.gaussian_renderer as gr
+    fast = {}
+    for tag, lazy, cull in (("", False, False), ("_lazy", True, False), ("_lazy_tile_cull", True, True)):
+        fm = train_host.ReferenceStyleModel(scene, dev, optimizer="fdgs")
+        fm.optimizer.lazy_forward = lazy
+        gr.render_options["tile_cull"] = cull
+        try:
+            def fstep():
+                for b in range(B):
+                    pkg = render(cams[b], fm, pipe, bg)
+                    (fused_l1_ssim(pkg["render"], gts[b], 0.2) / B).backward()
+                fm.optimizer.step()
+                fm.optimizer.zero_grad(set_to_none=True)
+
+            for _ in range(3):
+                fstep()
+            fast["images_s_fdgs_optim" + tag] = round(B * 1e3 / timed(fstep, max(n, 10)), 2)
+
+            def ffwd():
+                with torch.no_grad():
+                    render(cams[0], fm, pipe, bg)
+
+            if not tag:
+                fast["forward_ms_fdgs_optim"] = round(timed(ffwd, 16), 4)
+            fast["steps_skipped" + tag] = fm.optimizer.steps_skipped
+        finally:
+            gr.render_options["tile_cull"] = False
+        del fm
     return {"images_s": round(B * 1e3 / ms_step, 2), "ms_per_image": round(ms_step / B, 4), "forward_ms": round(ms_fwd, 4),
             "images_s_with_fused_loss": round(B * 1e3 / ms_step_fused, 2),
+            "fdgs_optim": dict(fast, what="the same loop with fdgs.optim.Adam (flat bucket behind the model's own Parameters, gradients "
+                                          "written straight into it, SH update from the staged views) + fused loss; _lazy: optimizer.lazy_forward "
+                                          "(no forward waits for num_rendered); _tile_cull: render_options['tile_cull']"),
             "pieces_ms": {"render_forward": round(ms_fwd, 4), "render_forward_backward_autograd": round(ms_fb, 4),
                           "pytorch_l1_ssim_forward_backward": round(ms_loss, 4), "torch_adam_step_per_step": round(ms_opt, 4)},
             "steps": n,

@@ -143,3 +143,18 @@ def test_product_never_imports_the_oracle():
                     if "oracle" in low:
                         assert not any(tok in low for tok in ("import", "#include", "cdll", "dlopen", "liboracle")), \
                             "%s references the oracle: %s" % (fn, ln.strip())
+
+
+def test_fdgs_adam_rejects_what_it_does_not_implement():
+    """fdgs.optim.Adam (the torch.optim.Optimizer of the drop-in path): no weight decay / amsgrad, no CPU parameters."""
+    import pytest
+    import torch
+    from fdgs.optim import Adam
+    p = torch.nn.Parameter(torch.zeros(4))
+    with pytest.raises(ValueError, match="weight_decay"):
+        Adam([{"params": [p], "name": "xyz"}], lr=0.0, weight_decay=0.1)
+    opt = Adam([{"params": [p], "name": "xyz"}], lr=0.0)
+    assert not opt.bucketable() and not opt.ensure_homed()
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        opt.step()
