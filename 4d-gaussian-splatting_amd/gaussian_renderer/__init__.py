@@ -92,7 +92,7 @@ def _fast_path(viewpoint_camera, pc, pipe, raster_settings, means2D):
     e = torch.Tensor([])
     opt = getattr(pc, "optimizer", None)
     prefilter_var = pc.prefilter_var if (is_4d and pc.prefilter_var > 0.0) else -1.0
-    if isinstance(opt, _FdgsAdam) and torch.is_grad_enabled() and opt.ensure_homed() and opt._homed["xyz"][0] is xyz:
+    if isinstance(opt, _FdgsAdam) and opt.ensure_homed() and opt._homed["xyz"][0] is xyz:
         tensors = opt.model_tensors(pc.gaussian_dim, pc.rot_4d)
         lazy = opt.lazy_forward
     else:

@@ -27,6 +27,7 @@ class SceneConfig(NamedTuple):
     rot_4d: bool
     gaussian_dim: int
     force_sh_3d: bool
+    cluster: float = 0.0   # fraction of the Gaussians drawn inside a box that covers 15 % of the image instead of the whole volume
 
 
 # BASELINE.json configs[0..4]
@@ -35,6 +36,10 @@ CONFIGS: Dict[str, SceneConfig] = {
     "C2": SceneConfig("C2", 100_000, 800, 800, 3, 0, 0.02, 1.0, True, 4, True),
     "C3": SceneConfig("C3", 300_000, 1352, 1014, 3, 2, 0.015, 10.0, True, 4, False),
     "C5": SceneConfig("C5", 2_000_000, 2704, 2028, 3, 0, 0.006, 1.0, True, 4, True),
+    # not a BASELINE config -- a skewed variant of C3: trained scenes (configs/dynerf/*.yaml) concentrate their Gaussians on the
+    # subject; 70 % of them in a box that projects onto 15 % of the image: tile lists five times the average there (thousands of
+    # entries, some beyond the 4096 the LDS sort takes), empty tiles elsewhere
+    "C3-clustered": SceneConfig("C3-clustered", 300_000, 1352, 1014, 3, 2, 0.015, 10.0, True, 4, False, 0.7),
     # not a BASELINE config -- a scaling probe: C3 with 4 x the Gaussians on 4 x the image area at the same footprint per
     # Gaussian (focal doubles with W, so s0 halves): every per-tile quantity equals C3's, every launch is 4 x larger --
     # what one launch per stage for 4 views of C3 would look like (tools/probe/README.md)
@@ -108,6 +113,13 @@ def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H:
         return torch.rand(*s, generator=g, dtype=torch.float32)
 
     xyz = (rand(P, 3) * 2.0 - 1.0) * 1.3
+    if cfg.cluster > 0.0:
+        # the first cluster * P Gaussians (then shuffled) sit in a box of sqrt(0.15) of the extent in x and y, off-centre
+        nc = int(cfg.cluster * P)
+        side = math.sqrt(0.15)
+        centre = torch.tensor([0.35, -0.2, 0.0]) * 1.3
+        xyz[:nc, 0:2] = centre[0:2] + xyz[:nc, 0:2] * side
+        xyz = xyz[torch.randperm(P, generator=g)]
     ts = (rand(P, 1) * 1.2 - 0.1) * dur
     scales = cfg.s0 * torch.exp(0.3 * randn(P, 3))
     scales_t = math.sqrt(0.2) * torch.exp(0.3 * randn(P, 1)) * dur

@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20,
                     help="untimed steps before anything is measured (the shader clock takes ~100 ms of load to settle)")
-    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5", "C3x4"])
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5", "C3x4", "C3-clustered"])
     ap.add_argument("--views-per-step", type=int, default=4,
                     help="views rendered per rank and optimizer step.  4 (default): the reference's DyNeRF batch per GPU "
                          "(configs/dynerf/*.yaml:7; gradients accumulated, train.py:104-166), weak scaling: global batch "
@@ -84,6 +84,9 @@ def parse_args():
                          "JSON line says how many steps that was (0: exactly --steps)")
     ap.add_argument("--reflists-steps", type=int, default=20,
                     help="steps of the extra leg with the reference's bit-identical tile lists (tile_cull = 0): value_reference_lists (0 = skip)")
+    ap.add_argument("--clustered-steps", type=int, default=10,
+                    help="workload C3 only: steps of the extra leg on C3-clustered (70 %% of the Gaussians on 15 %% of the image: tile lists of "
+                         "thousands of entries, some beyond the 4096 the LDS sort takes) -- what the skew of a trained scene costs (0 = skip)")
     ap.add_argument("--no-lazy", action="store_true",
                     help="A/B: every forward waits for its num_rendered (as the reference does) instead of fdgs_forward_out.lazy")
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
@@ -93,8 +96,12 @@ def parse_args():
                     help="N = 1 only: steps of the DROP-IN leg -- a reference-style model (separate parameters, torch.cat features, "
                          "PyTorch activations, torch.optim.Adam over 9 groups) through this package's render() + autograd + the "
                          "reference's PyTorch loss: what a user of the reference gets by swapping one import (0 = skip)")
-    ap.add_argument("--spatial-order", action="store_true",
-                    help="analysis: the whole run on the Morton-ordered model (train_host.spatial_sort before the warm-up); noted in config.workload")
+    ap.add_argument("--storage-order", choices=("morton", "random"), default="morton",
+                    help="how the model stores its Gaussians.  morton (default): in Morton order of their positions, what fdgs.harness.train "
+                         "keeps at the start and after every densification (train_host.spatial_sort; a memory layout, no effect on the arithmetic: "
+                         "the same images, DESIGN.md section 4.6b); random: the generator's order.  The other order is timed as a secondary leg "
+                         "(random_order_images_s / spatial_order_images_s)")
+    ap.add_argument("--spatial-order", action="store_true", help="(kept for old command lines) = --storage-order morton")
     ap.add_argument("--spatial-order-steps", type=int, default=20,
                     help="steps of the extra leg that re-times the step with the model stored in Morton order of the Gaussians' "
                          "positions (train_host.spatial_sort -- what fdgs.harness.train keeps after every densification) instead of the "
@@ -366,6 +373,9 @@ def main():
     model = train_host.GaussianParams(scene, dev)
     opt = train_host.make_optimizer(model)
     if args.spatial_order:
+        args.storage_order = "morton"
+    snap_random = (model.flat.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
+    if args.storage_order == "morton":
         train_host.spatial_sort(model, opt)
     pipe = train_host.PipelineFlags()
     B = max(1, args.views_per_step)
@@ -642,8 +652,14 @@ def main():
     # the same step with the model stored in Morton order (a memory-layout choice of the trainer, no effect on the arithmetic)
     spatial = None
     if use_pipeline and args.spatial_order_steps > 0:
-        restore()
-        train_host.spatial_sort(model, opt)
+        if args.storage_order == "morton":   # the other order: the generator's
+            model.flat.data.copy_(snap_random[0])
+            opt.exp_avg.copy_(snap_random[1])
+            opt.exp_avg_sq.copy_(snap_random[2])
+            opt.step_count = snap_random[3]
+        else:
+            restore()
+            train_host.spatial_sort(model, opt)
         for _ in range(3):
             step()
         torch.cuda.synchronize(dev)
@@ -665,8 +681,50 @@ def main():
             dtf = max_over_ranks(time.perf_counter() - tf0, world, dev)
         spatial = {"images_s": round(world * B * args.spatial_order_steps / dts, 2), "ms_per_step": round(dts / args.spatial_order_steps * 1e3, 4),
                    "forward_ms": round(dtf / n_fwd * 1e3, 4), "steps": args.spatial_order_steps,
-                   "what": "the same step and forward with the Gaussians stored in Morton order of their positions (train_host.spatial_sort; "
+                   "order": "random" if args.storage_order == "morton" else "morton",
+                   "what": "the same step and forward with the model stored in the OTHER order (`order`; `value` is measured with --storage-order "
+                           + args.storage_order + "): Morton order of the positions (train_host.spatial_sort; "
                            "fdgs.harness.train keeps the model that way): `value` is measured on the generator's random order"}
+
+    # a skewed scene: the same step on C3-clustered (own model; same storage order as the main run)
+    clustered = None
+    if use_pipeline and world == 1 and args.workload == "C3" and args.clustered_steps > 0:
+        cs = synth.make_scene(synth.CONFIGS["C3-clustered"], seed=0)
+        cm = train_host.GaussianParams(cs, dev)
+        co = train_host.make_optimizer(cm)
+        if args.storage_order == "morton":
+            train_host.spatial_sort(cm, co)
+        csnap = (cm.flat.detach().clone(), co.exp_avg.clone(), co.exp_avg_sq.clone())
+        cp = StepPipeline(cm, co, world_size=1, lambda_dssim=0.2, overlap=not args.no_overlap, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+        ccams = [train_host.SyntheticCamera(cs, dev, timestamp=(b + 0.5) / B * cs["time_duration"]) for b in range(B)]
+        for _ in range(3):
+            cres, _l = cp.step(ccams, gts, pipe, bg)
+        cm.flat.data.copy_(csnap[0]); co.exp_avg.copy_(csnap[1]); co.exp_avg_sq.copy_(csnap[2]); co.step_count = 0
+        torch.cuda.synchronize(dev)
+        tc0 = time.perf_counter()
+        for _ in range(args.clustered_steps):
+            cres, _l = cp.step(ccams, gts, pipe, bg)
+        torch.cuda.synchronize(dev)
+        dtc = time.perf_counter() - tc0
+        from fdgs.fused import raw_forward, raw_settings
+        with torch.no_grad():
+            tf0 = time.perf_counter()
+            for i in range(4 * args.clustered_steps):
+                rs_, (xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_) = raw_settings(ccams[i % B], cm, pipe, bg)
+                raw_forward(rs_, xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+            torch.cuda.synchronize(dev)
+            dtcf = time.perf_counter() - tf0
+            _capi.forward_lazy_status(dev, wait=True)
+            rs_, (xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_) = raw_settings(ccams[0], cm, pipe, bg)
+            one = raw_forward(rs_, xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_, tile_cull=not args.no_tile_cull)
+            torch.cuda.synchronize(dev)
+        clustered = {"images_s": round(B * args.clustered_steps / dtc, 2), "ms_per_step": round(dtc / args.clustered_steps * 1e3, 4),
+                     "forward_ms": round(dtcf / (4 * args.clustered_steps) * 1e3, 4), "num_rendered": int(one[0]), "steps": args.clustered_steps,
+                     "lazy_steps_redone": cp.lazy_redone,
+                     "what": "the same step on C3-clustered (fdgs.synth: 70 % of the 300 k Gaussians inside a box that projects onto 15 % of the image; "
+                             "188 tile lists beyond 4096 entries, the longest 5485 with the reference's lists): parity at full size in "
+                             "tests/test_gpu_parity.py::test_c3_clustered_full_size_vs_oracle"}
+        del cm, co, cp, csnap
 
     # host cost per view: the same step on a scene so small that the GPU work is negligible (wall time ~ host time)
     host_ms_per_view = None
@@ -755,7 +813,7 @@ def main():
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("[model stored in Morton order] " if args.spatial_order else "") + "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
+        "config": {"workload": ("[model stored in Morton order, as fdgs.harness.train keeps it] " if args.storage_order == "morton" else "[model stored in the generator's random order] ") + "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
                                                                         M, cfg.rot_4d, B, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else (", fused activations, explicit fwd/loss/bwd on %s" % ("one stream" if args.no_overlap else "two HIP streams") if use_pipeline else ", fused activations, autograd")),
                    "num_rendered": int(round(R_timed)), "tile_cull": not args.no_tile_cull, "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,
@@ -777,12 +835,21 @@ def main():
     if per_rank:
         out["per_rank"] = per_rank
     out["backend"] = backend if backend else "none (single process)"
+    if clustered:
+        out["clustered_images_s"] = clustered["images_s"]
+        out["clustered"] = clustered
     if reflists:
         out["value_reference_lists"] = reflists["images_s"]
         out["reference_lists"] = reflists
+    out["storage_order"] = args.storage_order
     if spatial:
-        out["spatial_order_images_s"] = spatial["images_s"]
-        out["spatial_order"] = spatial
+        if args.storage_order == "morton":
+            out["random_order_images_s"] = spatial["images_s"]
+            out["spatial_order_images_s"] = out["value"]
+        else:
+            out["spatial_order_images_s"] = spatial["images_s"]
+            out["random_order_images_s"] = out["value"]
+        out["other_storage_order"] = spatial
     if raster:
         out["raster_images_s"] = raster["images_s"]
         out["raster"] = raster

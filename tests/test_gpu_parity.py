@@ -352,6 +352,43 @@ def test_c3_full_size_vs_oracle(tile_cull, gpu_device):
     _timed_path_vs_oracle(synth.CONFIGS["C3"], gpu_device, 2, "C3", 1e-3, tile_cull=tile_cull)
 
 
+@pytest.mark.parametrize("tile_cull", [False, True])
+def test_c3_clustered_full_size_vs_oracle(tile_cull, gpu_device):
+    """A skewed C3 (fdgs.synth C3-clustered: 70 % of the 300 k Gaussians on 15 % of the image, the bench's `clustered` leg): 3.2 M
+    instances, 188 tile lists beyond the 4096 entries the LDS sort takes (global-scratch path), the longest 5485 -- forward lists bit
+    for bit (or, with tile_cull, instance by instance), pixels and all gradients against the oracle at the usual bar."""
+    scene = synth.make_scene(synth.CONFIGS["C3-clustered"], seed=0)
+    W, H = scene["W"], scene["H"]
+    o = pyoracle.Oracle(scene, kind="port")
+    ref = dict(o.forward())
+    ref["R"] = o.R
+    longest = int((ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]).max())
+    assert longest > 4096 and ref["R"] > 3_000_000
+    keep = torch.from_numpy(~ref["border"].astype(bool)).to(torch.float32)
+    grads = synth.make_upstream_grads(W, H, seed=1, scale=GRAD_SCALE)
+    grads = {k: v * keep.reshape((1,) * (v.dim() - 2) + (H, W)) for k, v in grads.items()}
+    hip, hipg = run_hip(scene, gpu_device, grads, tile_cull=tile_cull)
+    rep = check_forward(hip, ref, "C3-clustered", max_border=1e-3, tile_cull=tile_cull, WH=(W, H))
+    refg = {k: v.copy() for k, v in o.backward(grads["grad_color"], grads["grad_depth"], grads["grad_alpha"], grads["grad_flow"]).items()}
+    pyoracle.set_accumulation(1)
+    refg_rev = {k: v.copy() for k, v in o.backward(grads["grad_color"], grads["grad_depth"], grads["grad_alpha"], grads["grad_flow"]).items()}
+    pyoracle.set_accumulation(0)
+    o.close()
+    cov_chain = ("dL_dscale", "dL_dscale_t", "dL_drot", "dL_drot_r")
+    line = {}
+    for k, want in refg.items():
+        if k == "dL_dconic":
+            continue
+        got = hipg[k].reshape(want.shape)
+        scale = max(1.0, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        spread = float(np.abs(refg_rev[k] - want).max())
+        line[k] = "%.2e/%.1e" % (err, scale)
+        bound = max(1e-4 * scale, COV_CHAIN_K * spread) if k in cov_chain else 1e-4 * scale
+        assert err <= bound, "C3-clustered: %s max abs err %g > %g (max|ref| %g, the reference's own spread %g)" % (k, err, bound, scale, spread)
+    print("C3-clustered R", ref["R"], "longest list", longest, rep.get("instances", ""), line)
+
+
 def test_c5_full_size_forward_backward_vs_oracle(gpu_device):
     """BASELINE configs[4] (2 M Gaussians, 2704x2028, R = 15.9 M): forward AND backward at full size against the port oracle
     (reference backward.cu:926-1137 + :486-923), both blend-backward variants: all four upstream gradients (AUX) and
