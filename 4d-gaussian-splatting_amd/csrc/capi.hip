@@ -176,7 +176,7 @@ extern "C" int fdgs_version(void) { return FDGS_VERSION; }
 // how the forward calls of this process went: [0] everything enqueued ahead of num_rendered and kept, [1] ahead but sorted
 // again (longer lists than guessed), [2] exact sizes (first call of a thread, debug mode, or more instances than guessed)
 static std::atomic<long long> g_run_ahead[3];
-static std::atomic<bool> g_run_ahead_enabled{true};
+static std::atomic<bool> g_run_ahead_enabled{[]() { const char* e = getenv("FDGS_RUN_AHEAD"); return !(e && e[0] == '0'); }()};   // FDGS_RUN_AHEAD=0: as fdgs_set_run_ahead(0)
 constexpr int FDGS_MAX_DEVICES = 64;   // = the size of g_box_of
 constexpr int FDGS_GUESS_SLOTS = 8;    // = the size of g_guesses
 extern "C" void fdgs_set_run_ahead(int32_t enable) { g_run_ahead_enabled.store(enable != 0); }
@@ -210,12 +210,15 @@ namespace
 		g.longest = longest + longest / 4;
 		g.r_hist[g.hist_at & 3] = R; g.l_hist[g.hist_at & 3] = longest; g.hist_at++;
 	}
-	// Reads the reports of this thread's pending forwards, oldest first.  wait: block until all of them (or, with upto != 0, all
-	// up to that sequence number) are in; otherwise stop at the first one that has not reported.  stream (optional): polled now and
-	// then while waiting, so that a failed launch ends the wait.  Returns false when a report never showed up.
+	// Reads the reports of this thread's pending forwards, oldest first, up to sequence number `upto` (inclusive; HARVEST_ALL: every
+	// forward handed a number so far -- only where all of them are REGISTERED, i.e. not between ++box.seq and the registration of
+	// that forward's record: the loop would step over the unregistered number and the forward's own wait would find nothing to
+	// wait for).  wait: block until they are in; otherwise stop at the first one that has not reported.  stream (optional): polled
+	// now and then while waiting, so that a failed launch ends the wait.  Returns false when a report never showed up.
+	constexpr unsigned long long HARVEST_ALL = ~0ull;
 	bool harvest(Mailbox& box, bool wait, unsigned long long upto, hipStream_t stream, bool have_stream)
 	{
-		while (box.head <= box.seq && (upto == 0 || box.head <= upto))
+		while (box.head <= box.seq && box.head <= upto)
 		{
 			MailRec& r = box.rec[box.head % MAIL_SLOTS];
 			if (!r.pending || r.seq != box.head) { box.head++; continue; }
@@ -262,7 +265,7 @@ extern "C" int fdgs_forward_lazy_status(int32_t wait, void* stream_v, int32_t* p
 		return FDGS_OK;
 	}
 	Mailbox& box = *g_box_of[dev_id];
-	if (box.host && !harvest(box, wait != 0, 0, (hipStream_t)stream_v, stream_v != nullptr))
+	if (box.host && !harvest(box, wait != 0, HARVEST_ALL, (hipStream_t)stream_v, stream_v != nullptr))
 		return fail(FDGS_ERR_HIP, "a lazy forward never reported num_rendered (failed launch?)");
 	int left = 0;
 	for (unsigned long long q = box.head; q <= box.seq; q++) if (box.rec[q % MAIL_SLOTS].pending && box.rec[q % MAIL_SLOTS].seq == q) left++;
@@ -378,9 +381,11 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
 	}
 	// reports that are in by now refresh the guesses; the slot this call takes must be free (at most MAIL_SLOTS unreported forwards)
-	if (!harvest(box, false, 0, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
+	if (!harvest(box, false, HARVEST_ALL, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
 	const unsigned long long seq = ++box.seq;
-	if (seq >= MAIL_SLOTS && !harvest(box, true, seq - MAIL_SLOTS, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
+	// (from here to the registration of this call's record below, box.seq counts a forward that has no record yet: harvest only up
+	// to older numbers)
+	if (seq > MAIL_SLOTS && !harvest(box, true, seq - MAIL_SLOTS, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
 	const int slot = (int)(seq % MAIL_SLOTS);
 	const uint32_t ticket = ticket_of(seq);
 	volatile uint32_t* const mail = box.host + 4 * slot;
@@ -461,6 +466,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
 		if (!harvest(box, true, seq, stream, false)) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
 	}
+	if (rec.pending || __atomic_load_n(&mail[2], __ATOMIC_ACQUIRE) != ticket) return fail(FDGS_ERR_HIP, "internal: the forward's own report was not read");
 	const int R = (int)mail[0], longest = (int)mail[1];
 	if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");
 	*num_rendered = R;

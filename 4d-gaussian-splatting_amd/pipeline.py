@@ -51,7 +51,8 @@ class StepPipeline:
         # turned out too small (its image is invalid) sends the whole step through the waiting path again -- nothing irreversible has
         # happened by then: the gradient bucket and the SH stages are simply overwritten.  ``lazy_redone`` counts those steps.
         # Several ranks: off (the decision to start over would have to be collective).
-        self.lazy = bool(lazy)
+        import os
+        self.lazy = bool(lazy) and os.environ.get("FDGS_PIPELINE_LAZY", "1") != "0"   # FDGS_PIPELINE_LAZY=0: debugging switch
         self.lazy_redone = 0
         # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
         # is bracketed by two timing events appended to it (train_host.timed_wait): the exchange time nothing overlapped
@@ -87,7 +88,10 @@ class StepPipeline:
 
     def _upstream(self, B):
         if B not in self._up:
-            self._up[B] = torch.full((1,), 1.0 / (B * self.world), dtype=torch.float32, device=self.dev)
+            # filled on the stream that reads it (B): created on the caller's stream AFTER sB.wait_stream(main) had been recorded, the
+            # fill raced with the first step's loss backward
+            with torch.cuda.stream(self.sB):
+                self._up[B] = torch.full((1,), 1.0 / (B * self.world), dtype=torch.float32, device=self.dev)
         return self._up[B]
 
     def step(self, cams: Sequence, gts: Sequence[torch.Tensor], pipe, bg: torch.Tensor, scaling_modifier: float = 1.0):

@@ -677,3 +677,50 @@ def test_lazy_forward_matches_waiting_forward_and_reports_overflow(gpu_device):
     pend, failed, reported = _capi.forward_lazy_status(gpu_device, wait=True)
     assert res_big2[0] == -1 and failed == 0 and reported == [sync_big[0]]
     np.testing.assert_array_equal(collect_forward((sync_big[0],) + tuple(res_big2[1:]), P, W, H)["out_color"], collect_forward(sync_big, P, W, H)["out_color"])
+
+
+def test_mailbox_ring_wraps_correctly_in_a_fresh_thread(gpu_device):
+    """The tile scans report num_rendered through a ring of 64 pinned slots per host thread and device.  A fresh thread issues 70
+    waiting and 70 lazy forwards: every one of them -- the 64th and 65th in particular, where the ring wraps -- must return /
+    report the right count and render the same image (regression: the 64th forward of a thread used to read its slot before the
+    scan had written it, returned num_rendered = 0 whenever the host was faster than the kernel, and the backward that was handed
+    that 0 skipped the view)."""
+    import threading
+    from fdgs import _capi
+    from fdgs.gaussian_renderer.diff_gaussian_rasterization import _C
+    from util import native_args_fwd, scene_to_device
+    scene = synth.make_scene(SC("ring", 3000, 160, 128, 0, 0, 0.03, 1.0, True, 4, True), seed=12)
+    sc = scene_to_device(scene, gpu_device)
+    want = _C.rasterize_gaussians(*native_args_fwd(sc))
+    torch.cuda.synchronize()
+    out = {}
+
+    def work():
+        try:
+            torch.cuda.set_device(gpu_device)
+            rs, bad = [], 0
+            for i in range(70):
+                res = _C.rasterize_gaussians(*native_args_fwd(sc))
+                rs.append(res[0])
+                bad += int(not torch.equal(res[1], want[1]))
+            lazy_r = []
+            for i in range(70):
+                res = _C.rasterize_gaussians(*native_args_fwd(sc), lazy=True)
+                assert res[0] == -1
+                bad += int(not torch.equal(res[1], want[1]))
+                if i % 16 == 15:
+                    pend, failed, reported = _capi.forward_lazy_status(gpu_device, wait=True)
+                    assert failed == 0 and pend == 0
+                    lazy_r += reported
+            pend, failed, reported = _capi.forward_lazy_status(gpu_device, wait=True)
+            lazy_r += reported
+            out.update(rs=rs, lazy_r=lazy_r, bad=bad, failed=failed)
+        except Exception as e:   # surfaces in the main thread
+            out["error"] = repr(e)
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "error" not in out, out.get("error")
+    assert out["rs"] == [want[0]] * 70, out["rs"]
+    assert out["lazy_r"] == [want[0]] * 70 and out["failed"] == 0 and out["bad"] == 0, (out["lazy_r"], out["bad"])
