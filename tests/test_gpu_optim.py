@@ -55,14 +55,16 @@ def test_render_fast_path_equals_the_reference_sequence(cfg, gpu_device):
         grads[fast]["viewspace"] = pkg["viewspace_points"].grad.detach().clone()
     # The kernels' activations agree with PyTorch's to an ulp or two (tests/test_gpu_api.py::test_render_raw_matches_render holds
     # the raw-parameter path to the oracle with bit-identical activations); an ulp in a scale or an opacity moves a handful of
-    # alpha >= 1/255 / radius = ceil(3 sigma) decisions: <= 1e-5 of the output's scale on all but 1e-3 of the pixels, a flipped
+    # alpha >= 1/255 / radius = ceil(3 sigma) decisions: <= 1e-4 of the output's scale on all but 1e-3 of the pixels, a flipped
     # pixel by at most 1/255 of a colour.
     flips = int((out[True]["radii"] != out[False]["radii"]).sum())
     assert flips <= max(2, cfg.P // 2000), flips
     for k in ("render", "depth", "alpha"):
-        tol = 1e-5 * max(1.0, float(out[False][k].abs().max()))
+        # (rot_4d: the conditional covariance is a difference of O(scale^2) terms -- it amplifies the ulp, as it amplifies rounding
+        # in the backward, tests/test_gpu_parity.py -- so the bar is the pixel bar of the parity tests, 1e-4, not 1e-5)
+        tol = 1e-4 * max(1.0, float(out[False][k].abs().max()))
         d = (out[True][k] - out[False][k]).abs()
-        assert float((d > tol).float().mean()) <= 1e-3 and float(d.max()) <= 2e3 * tol, (k, float((d > tol).float().mean()), float(d.max()))
+        assert float((d > tol).float().mean()) <= 1e-3 and float(d.max()) <= 2e2 * tol, (k, float((d > tol).float().mean()), float(d.max()))
     for n, g in grads[False].items():
         scale = max(1.0, float(g.abs().max()))
         d = (grads[True][n] - g).abs()
