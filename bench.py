@@ -338,7 +338,7 @@ def pmc_valu(stage):
             t = line.split()
             if not line.startswith(" ") and t:
                 cur = line.strip()
-            elif cur and stage in cur and len(t) >= 2 and t[0].startswith("SQ_"):
+            elif cur and stage in cur and len(t) >= 2 and (t[0].startswith("SQ_") or t[0] == "_AVG_DURATION_NS"):
                 vals[t[0]] = float(t[1])
         if "SQ_ACTIVE_INST_VALU" not in vals:
             return None
@@ -347,6 +347,8 @@ def pmc_valu(stage):
         return {"counters_from": "committed pass (not this run): " + os.path.relpath(files[-1], ROOT),
                 "insts_valu_per_launch": int(vals.get("SQ_INSTS_VALU", 0)),
                 "valu_issue_cycles_per_simd": int(vals["SQ_ACTIVE_INST_VALU"] * 4 / simds),
+                # the kernel's duration in the counter pass itself (its views' lists differ a little from the timed region's mean)
+                "kernel_ns_in_counter_pass": vals.get("_AVG_DURATION_NS"),
                 "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
@@ -682,9 +684,9 @@ def main():
         spatial = {"images_s": round(world * B * args.spatial_order_steps / dts, 2), "ms_per_step": round(dts / args.spatial_order_steps * 1e3, 4),
                    "forward_ms": round(dtf / n_fwd * 1e3, 4), "steps": args.spatial_order_steps,
                    "order": "random" if args.storage_order == "morton" else "morton",
-                   "what": "the same step and forward with the model stored in the OTHER order (`order`; `value` is measured with --storage-order "
-                           + args.storage_order + "): Morton order of the positions (train_host.spatial_sort; "
-                           "fdgs.harness.train keeps the model that way): `value` is measured on the generator's random order"}
+                   "what": "the same step and forward with the model stored in the OTHER order (`order`); `value` is measured with "
+                           "--storage-order " + args.storage_order + ". morton = Morton order of the positions (train_host.spatial_sort, "
+                           "the order fdgs.harness.train keeps the model in); random = the generator's order"}
 
     # a skewed scene: the same step on C3-clustered (own model; same storage order as the main run)
     clustered = None
@@ -778,8 +780,11 @@ def main():
     dom_bytes = ALGO_BYTES[dom](P, Pv, M, R_timed, N, T)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
-                "traffic_source": "committed rocprofv3 --pmc passes of the same command (profiles/pmc_traffic_r*.json, tools/pmc_traffic.py), not this run",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # the committed counter passes are C3 passes: no figure for another workload
+                "traffic": pmc_traffic(dom) if cfg.name == "C3" else None,
+                "traffic_source": ("committed rocprofv3 --pmc passes of the same step (profiles/pmc_traffic_r*.json: tools/collect_profiles.sh, "
+                                   "tools/pmc_traffic.py), not this run" if cfg.name == "C3" else None),
                 "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"],
                 "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
@@ -790,7 +795,10 @@ def main():
     if valu:
         # instruction counts are a property of the kernel + workload (committed SQ pass, same C3 scene); the time and the clock are live
         ghz = shader_ghz if shader_ghz else 2.4
-        valu["kernel_cycles"] = int(dom_ms * 1e-3 * ghz * 1e9)
+        pass_ns = valu.get("kernel_ns_in_counter_pass")
+        valu["kernel_cycles"] = int((pass_ns * 1e-9 if pass_ns else dom_ms * 1e-3) * ghz * 1e9)
+        valu["kernel_cycles_from"] = ("the kernel's duration in the counter pass x the clock measured live" if pass_ns
+                                      else "the kernel's live duration x the clock measured live")
         valu["clock"] = ("measured during the timed steps (s_memtime / s_memrealtime sampler, fdgs_debug_clock_sample)" if shader_ghz
                          else "2.4 GHz maximum clock assumed: valu_issue_frac is a LOWER bound")
         roofline["valu"] = valu

@@ -14,8 +14,15 @@ for fn in glob.glob("$OUT/p*/*counter_collection.csv"):
         k = r["Kernel_Name"].split("(")[0]
         if not any(t in k for t in ("blend", "preprocess", "ssim", "sh_bwd", "tile_")): continue
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+# the kernels' durations in the pass that counted SQ_ACTIVE_INST_VALU (p2): the issue fraction is counted cycles / THESE durations
+dur = collections.defaultdict(list)
+for fn in glob.glob("$OUT/p2/*kernel_trace.csv"):
+    for r in csv.DictReader(open(fn)):
+        dur[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(tot):
     print(k)
+    if dur.get(k):
+        print("   %-26s %16.0f per launch" % ("_AVG_DURATION_NS", sum(dur[k]) / len(dur[k])))
     for c in sorted(tot[k]):
         print("   %-26s %16.0f per launch" % (c, tot[k][c] / max(len(n[(k, c)]), 1)))
 PY
