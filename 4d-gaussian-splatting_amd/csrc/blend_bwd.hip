@@ -170,7 +170,12 @@ namespace fdgs
 			"v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 			"v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 			"v_cndmask_b32_e64 %0, %0, %2, %19"
-			: "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]), "+&v"(a[3]), "+&v"(a[4]), "+&v"(a[5]), "+&v"(a[6]), "+&v"(a[7]), "+&v"(a[8])   // early-clobber: b[] is read after a[] has been written
+			// Operand constraints: b[] is read after a[] has been written.  a[k] are tied in/out operands -- each holds a live input on
+			// entry, so the allocator can only give a[j] and b[k] one register if they are the SAME value; the callers pass the .x and
+			// .y halves of packed products of two different list entries (entry_pair), never one value twice.  The formally safe forms
+			// were built and cost the both-alive path 8 ("+&v" on a[]: the early-clobber is applied to the whole 64-bit pair register
+			// the packed products live in) or 6 (b[] as in/out operands) v_mov per pair: 272 -> 282 us per launch at C3.
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
 			: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "s"(m1), "s"(m0));
 	}
 
@@ -235,7 +240,8 @@ namespace fdgs
 			"v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 			"v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 			"v_cndmask_b32_e64 %0, %0, %2, %25"
-			: "+&v"(a[0]), "+&v"(a[1]), "+&v"(a[2]), "+&v"(a[3]), "+&v"(a[4]), "+&v"(a[5]), "+&v"(a[6]), "+&v"(a[7]), "+&v"(a[8]), "+&v"(a[9]), "+&v"(a[10]), "+&v"(a[11])
+			// (operand constraints: see pair_row_reduce9)
+			: "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
 			: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "v"(b[10]), "v"(b[11]), "s"(m1), "s"(m0));
 	}
 
