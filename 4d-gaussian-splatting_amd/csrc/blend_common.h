@@ -72,34 +72,30 @@ namespace fdgs
 	// reach alpha >= 1/255 at some point of the rectangle [rx0,rx1] x [ry0,ry1] (pixel centres)?
 	// alpha = opacity * exp(-q), q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  ==>  need min q <= ln(255 opacity).
 	// The minimum of the convex q over the rectangle is 0 if the mean is inside, otherwise it lies
-	// on one of the four edges (1-D quadratics, clamped).  Slack 0.05 in q (5 % in alpha) covers
+	// on an edge that faces the mean (1-D quadratics, clamped).  Slack 0.05 in q (5 % in alpha) covers
 	// every rounding difference to the per-pixel evaluation; degenerate conics are never culled.
 	__device__ __forceinline__ bool block_reaches(const float4 a, const float4 b, float rx0, float rx1, float ry0, float ry1)
 	{
 		const float A = a.z, B = a.w, Cc = b.x, op = b.y;
 		if (!(op >= 0.0039f)) return false;                 // alpha <= opacity < 1/255 (1/255 = 0.003922)
-		if (!(A > 0.0f && Cc > 0.0f)) return true;
-		const float tau = __logf(255.0f * op) + 0.05f;
+		// degenerate conics, and conics that are not positive definite with a margin (a needle of 300 : 1 whose determinant has
+		// lost its bits): never culled -- what follows needs q convex
+		if (!(A > 0.0f && Cc > 0.0f && A * Cc > 1.00001f * (B * B))) return true;
 		const float dx0 = rx0 - a.x, dx1 = rx1 - a.x, dy0 = ry0 - a.y, dy1 = ry1 - a.y;
-		if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
+		const bool xin = dx0 <= 0.0f && dx1 >= 0.0f, yin = dy0 <= 0.0f && dy1 >= 0.0f;
+		if (xin && yin) return true;
+		// 255 op >= 0.99: normal range; v_log_f32 (log2, 1 ulp) is exact enough by five orders of magnitude for a bound with 0.05 of slack
+		const float tau = __builtin_amdgcn_logf(255.0f * op) * 0.69314718056f + 0.05f;
+		// A convex q takes its minimum over the rectangle on an edge that FACES the mean (the mean strictly beyond the edge's
+		// line: at the minimiser p the direction towards the mean leaves the rectangle, and it can only leave it through a
+		// constraint that is active at p).  That is at most one vertical and one horizontal edge.
+		const float ex = dx0 > 0.0f ? dx0 : dx1, ey = dy0 > 0.0f ? dy0 : dy1;
 		const float invA = __builtin_amdgcn_rcpf(A), invC = __builtin_amdgcn_rcpf(Cc);
-		float qmin;
-		{
-			const float dy = fminf(fmaxf(-B * dx0 * invC, dy0), dy1);
-			qmin = 0.5f * (A * dx0 * dx0 + Cc * dy * dy) + B * dx0 * dy;
-		}
-		{
-			const float dy = fminf(fmaxf(-B * dx1 * invC, dy0), dy1);
-			qmin = fminf(qmin, 0.5f * (A * dx1 * dx1 + Cc * dy * dy) + B * dx1 * dy);
-		}
-		{
-			const float dx = fminf(fmaxf(-B * dy0 * invA, dx0), dx1);
-			qmin = fminf(qmin, 0.5f * (A * dx * dx + Cc * dy0 * dy0) + B * dx * dy0);
-		}
-		{
-			const float dx = fminf(fmaxf(-B * dy1 * invA, dx0), dx1);
-			qmin = fminf(qmin, 0.5f * (A * dx * dx + Cc * dy1 * dy1) + B * dx * dy1);
-		}
+		const float dyv = __builtin_amdgcn_fmed3f(-B * ex * invC, dy0, dy1);   // clamp (dy0 <= dy1)
+		const float qv = 0.5f * (A * ex * ex + Cc * dyv * dyv) + B * ex * dyv;
+		const float dxh = __builtin_amdgcn_fmed3f(-B * ey * invA, dx0, dx1);
+		const float qh = 0.5f * (A * dxh * dxh + Cc * ey * ey) + B * dxh * ey;
+		const float qmin = fminf(xin ? 3.0e38f : qv, yin ? 3.0e38f : qh);
 		return qmin <= tau;
 	}
 }
