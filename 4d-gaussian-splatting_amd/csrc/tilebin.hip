@@ -30,7 +30,8 @@
 //              inside every splitter interval, then every entry counts the smaller keys of its bucket; 128 / 256 / 512
 //              threads per tile for lists of up to 1024 / 2048 / 4096 entries.  When a bucket is still crowded (a pile
 //              of equal depths) the tile falls back to a bitonic sort of the 64-bit keys in LDS.
-//   n  > 4096  bitonic sort in global scratch (R keys, requested from the allocator only when such a list exists).
+//   n <= 16384 the same with 1024 threads per tile (8 or 16 keys per thread) for the few long lists of a clustered scene.
+//   n  > 16384 bitonic sort in global scratch (R keys, requested from the allocator only when such a list exists).
 #include "fdgs_common.h"
 
 namespace fdgs
@@ -321,9 +322,11 @@ namespace fdgs
 	constexpr int TS_NS = 64;                   // splitters
 	constexpr int TS_G = 2;                     // keys a thread handles side by side (independent LDS chains in flight); 4 wastes half of
 	                                            // the lanes on the typical 470-entry list of a 256-thread instance, 1 serialises the chains
-	constexpr int TS_ITEMS = 8;                 // keys per thread (four groups of TS_G)
-	constexpr int TS_LARGE = 512 * TS_ITEMS;    // 4096: the longest list sorted in LDS (128 / 256 / 512 threads per tile by length)
+	constexpr int TS_ITEMS = 8;                 // keys per thread (four groups of TS_G) of the 128 / 256 / 512-thread instances
+	constexpr int TS_ITEMS_LONG = 16;           // ... of the 1024-thread instance for the longest lists
+	constexpr int TS_LARGE = 1024 * TS_ITEMS_LONG;   // 16384: the longest list sorted in LDS (128 KiB of keys + ids: one tile per CU)
 	constexpr int TS_DIRECT = 96;               // lists this short skip the bucketing
+	constexpr int TS_ENDS = 1024;               // lists longer than this subdivide the two end intervals too (tile_sort_one)
 	typedef unsigned long long u64;
 
 	__device__ __forceinline__ int pow2_ceil(int n)
@@ -368,43 +371,27 @@ namespace fdgs
 #else
 #define TL_MARK(k) do { } while (0)
 #endif
-	constexpr int TS_SUB = 8;                           // linear sub-buckets inside every splitter interval
-	constexpr int TS_NBK = (TS_NS + 1) * TS_SUB;        // 260 buckets
 	constexpr int TS_PAD = 128;                         // sentinel keys behind the list (>= the largest rank_max)
 
-	template <int THREADS>
-	__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
-	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
-	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
-	                                                           int lds_cap, int rank_max, const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                           int last /* no further instance takes what this one leaves */,
-	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T, int band)
+	// One tile's list.  Returns true when the list is no longer than n_lo (not this instance's).
+	template <int THREADS, int ITEMS>
+	__device__ __forceinline__ bool tile_sort_one(const int tile, const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
+	                                              uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, u64* __restrict__ big_scratch,
+	                                              const int n_lo, const int lds_cap, const int rank_max, const int last)
 	{
-		// Which tile: with `order` (the blend kernels' tile order, written by the scatter launch: inside every XCD's band of tiles
-		// the longest lists first) workgroup b takes slot (b % 8) * band + b / 8 of it -- the long lists start first and the launch
-		// ends on short ones; without: tile b.
-		int tile = (int)blockIdx.x;
-		if (order != nullptr)
-		{
-			const int slot = ((int)blockIdx.x % NUM_XCDS_BIN) * band + (int)blockIdx.x / NUM_XCDS_BIN;
-			if ((int)blockIdx.x / NUM_XCDS_BIN >= band || slot >= T) return;
-			tile = (int)order[slot];
-		}
-		else if (tile >= T) return;
-		// launched before the host knew num_rendered: if the buffers are too small the scatter pass did not run either (the counters
-		// are not list ends) -- every tile is reported empty, so that whatever is queued behind reads nothing, and the host starts over
-		if (ctl[0] > capacity)
-		{
-			if (n_lo == 0 && threadIdx.x == 0) ranges[tile] = make_uint2(0u, 0u);
-			return;
-		}
 		// LDS: lds_cap + TS_PAD depth keys, then lds_cap ids, in bucket order (8 lds_cap + 4 TS_PAD bytes); the same
 		// bytes hold the 64-bit keys of the bitonic fall-back and, at the end, the ids in final order
 		extern __shared__ uint32_t s_dyn[];
 		__shared__ uint32_t s_split[TS_NS];
+		constexpr int GROUPS = ITEMS / TS_G;
+		// linear sub-buckets inside every splitter interval: 8 for the 128- / 256-thread instances (520 buckets for up to 2048 keys), 32
+		// for the long-list instances (measured on tiles of 3000 / 6000 / 12 000 keys with 8 | 16 | 32: 58 | 45 | 43, 176 | 126 | 100,
+		// 648 | 479 | 291 us per 1024 tiles; the short lists of C3 lose 1 us with 16)
+		constexpr int TS_SUB = THREADS >= 512 ? 32 : 8;
+		constexpr int TS_NBK = (TS_NS + 1) * TS_SUB;
 		__shared__ uint32_t s_hist[TS_NBK + 4];    // bucket sizes -> starts; [TS_NBK] = n
 		__shared__ uint32_t s_flag[2];             // largest bucket, depth ties seen
-		constexpr int ITEMS = TS_ITEMS, GROUPS = ITEMS / TS_G;
+		__shared__ uint32_t s_wmin[THREADS / WAVE], s_wmax[THREADS / WAVE];   // smallest / largest depth bits per wave (long lists)
 		const int tid = threadIdx.x, lane = tid & 63;
 		// after the scatter pass a tile's counter holds the END of its list = the start of the next tile's
 #ifdef FDGS_TS_TIMELINE
@@ -414,11 +401,11 @@ namespace fdgs
 		const uint32_t end = list_end[tile];
 		const int n = (int)(end - start);
 		if (n_lo == 0 && tid == 0) ranges[tile] = n > 0 ? make_uint2(start, end) : make_uint2(0u, 0u);   // identifyTileRanges leaves empty tiles at the memset's (0,0)
-		if (n <= n_lo) return;
+		if (n <= n_lo) return true;
 		if (n == 1)
 		{
 			if (tid == 0) point_list[start] = pairs[start].y;
-			return;
+			return false;
 		}
 		if (n > lds_cap)
 		{
@@ -428,7 +415,7 @@ namespace fdgs
 				// host repeats with the right instances -- the ids go out unsorted, so that the blend queued behind reads valid ones
 				if (last)
 					for (int i = tid; i < n; i += THREADS) point_list[start + i] = pairs[start + i].y;
-				return;
+				return false;
 			}
 			// a list longer than the LDS takes: bitonic sort in global scratch (slot s of the list = slot start + s)
 			volatile u64* S = big_scratch + start;
@@ -440,7 +427,7 @@ namespace fdgs
 			__syncthreads();
 			bitonic_sort<THREADS>(S, n);
 			for (int i = tid; i < n; i += THREADS) point_list[start + i] = (uint32_t)S[i];
-			return;
+			return false;
 		}
 		uint32_t* s_key = s_dyn;                          // [lds_cap + TS_PAD]
 		uint32_t* s_id = s_dyn + lds_cap + TS_PAD;        // [lds_cap]
@@ -473,6 +460,20 @@ namespace fdgs
 		TL_MARK(0);
 		for (int i = tid; i < TS_NBK + 4; i += THREADS) s_hist[i] = 0u;
 		if (tid < 2) s_flag[tid] = 0u;
+		// The intervals below the first and above the last splitter have no second bound among the samples; each holds n / 65
+		// keys on average -- 92 at n = 6000, where the bucket they used to be went over rank_max and sent every such tile to the
+		// bitonic fall-back.  Lists beyond TS_ENDS keys take the smallest / largest key of the list as the missing bounds and
+		// subdivide these two intervals like the others.
+		const bool ends = n > TS_ENDS;
+		if (ends)
+		{
+			uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+			for (int i = 0; i < ITEMS; i++) { mn = min(mn, key[i]); mx = max(mx, key[i] == 0xFFFFFFFFu ? 0u : key[i]); }   // (unused slots hold 0xFFFFFFFF)
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+			if (lane == 0) { s_wmin[tid >> 6] = mn; s_wmax[tid >> 6] = mx; }
+		}
 		if (!direct && tid < WAVE)
 		{
 			// the depth bits of 64 regularly spaced entries, sorted across the lanes of wave 0: the splitters
@@ -499,6 +500,13 @@ namespace fdgs
 		if (!direct)
 		{
 			const uint32_t last = s_split[TS_NS - 1];
+			uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+			if (ends)
+			{
+#pragma unroll
+				for (int w = 0; w < THREADS / WAVE; w++) { kmin = min(kmin, s_wmin[w]); kmax = max(kmax, s_wmax[w]); }
+			}
+			const uint32_t first = s_split[0];
 #pragma unroll
 			for (int step = TS_NS / 2; step > 0; step >>= 1)
 			{
@@ -509,9 +517,11 @@ namespace fdgs
 				uint32_t b = br[it];
 				if (last < k) b = TS_NS;
 				uint32_t sub = 0;
-				if (b > 0 && b < TS_NS)
+				if ((b > 0 && b < TS_NS) || ends)
 				{
-					const uint32_t lo = s_split[b - 1]; const uint32_t hi = s_split[b];   // lo < k <= hi
+					// lo < k <= hi (below the first splitter: kmin - 1 < k <= first; above the last: last < k <= kmax)
+					const uint32_t lo = b == 0 ? kmin - 1u : s_split[b - 1];
+					const uint32_t hi = b == 0 ? first : (b == TS_NS ? kmax : s_split[min(b, (uint32_t)TS_NS - 1u)]);
 					sub = min((uint32_t)TS_SUB - 1u, (uint32_t)((float)(k - lo - 1u) * ((float)TS_SUB * __builtin_amdgcn_rcpf((float)(hi - lo)))));
 				}
 				br[it] = b * TS_SUB + sub;)
@@ -558,7 +568,7 @@ namespace fdgs
 			__syncthreads();
 			bitonic_sort<THREADS>(s_a, n);
 			for (int i = tid; i < n; i += THREADS) point_list[start + i] = (uint32_t)s_a[i];
-			return;
+			return false;
 		}
 
 		// keys / ids into LDS in bucket order; TS_PAD sentinels behind the list
@@ -574,13 +584,23 @@ namespace fdgs
 #pragma unroll
 		for (int i = 0; i < ITEMS; i++) { bs[i] = (uint32_t)n; lt[i] = 0; eq[i] = 0; }
 		FOR_ITEMS(if (valid) { const uint32_t b = br[it] >> 16; bs[it] = s_hist[b]; maxlen = max(maxlen, s_hist[b + 1] - bs[it]); })
-		for (uint32_t k = 0; k < maxlen; k++)
+		// Four positions of every bucket per trip: the trip is one LDS round trip (all of a thread's reads in flight together) plus
+		// the counting, and the round trip was most of it (the loop was 30 k of the 54 k cycles a 2048-key tile takes, whatever the
+		// bucket sizes).  Up to three positions beyond maxlen are read: later buckets or sentinels (rank_max + 3 <= TS_PAD).
+		for (uint32_t k = 0; k < maxlen; k += 4)
 		{
 			FOR_ITEMS(
-				const uint32_t kj = s_key[bs[it] + k];
-				asm("v_cmp_lt_u32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
-				    "v_cmp_eq_u32 vcc, %2, %3\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-				    : "+v"(lt[it]), "+v"(eq[it]) : "v"(kj), "v"(key[it]) : "vcc");)
+				const uint32_t* q = s_key + bs[it] + k;
+				const uint32_t k0 = q[0]; const uint32_t k1 = q[1]; const uint32_t k2 = q[2]; const uint32_t k3 = q[3];
+				asm("v_cmp_lt_u32 vcc, %2, %6\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+				    "v_cmp_eq_u32 vcc, %2, %6\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+				    "v_cmp_lt_u32 vcc, %3, %6\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+				    "v_cmp_eq_u32 vcc, %3, %6\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+				    "v_cmp_lt_u32 vcc, %4, %6\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+				    "v_cmp_eq_u32 vcc, %4, %6\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+				    "v_cmp_lt_u32 vcc, %5, %6\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+				    "v_cmp_eq_u32 vcc, %5, %6\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+				    : "+v"(lt[it]), "+v"(eq[it]) : "v"(k0), "v"(k1), "v"(k2), "v"(k3), "v"(key[it]) : "vcc");)
 		}
 		uint32_t fin[ITEMS];
 #pragma unroll
@@ -604,6 +624,36 @@ namespace fdgs
 		for (int i = tid; i < n; i += THREADS) point_list[start + i] = s_out[i];
 		TL_MARK(8);
 #undef FOR_ITEMS
+		return false;
+	}
+
+	// The main instance (n_lo == 0: every tile, also writes `ranges`): workgroup b takes ONE tile -- with `order` (the blend kernels'
+	// tile order, written by the scatter launch: inside every XCD's band of tiles the longest lists first) slot (b % 8) * band + b / 8
+	// of it, so that the long lists start first and the launch ends on short ones; without: tile b.
+	template <int THREADS, int ITEMS>
+	__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
+	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
+	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
+	                                                           int lds_cap, int rank_max, const uint32_t* __restrict__ ctl, uint32_t capacity,
+	                                                           int last /* no further instance takes what this one leaves */,
+	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T, int band)
+	{
+		int tile = (int)blockIdx.x;
+		if (order != nullptr)
+		{
+			const int slot = ((int)blockIdx.x % NUM_XCDS_BIN) * band + (int)blockIdx.x / NUM_XCDS_BIN;
+			if ((int)blockIdx.x / NUM_XCDS_BIN >= band || slot >= T) return;
+			tile = (int)order[slot];
+		}
+		else if (tile >= T) return;
+		// launched before the host knew num_rendered: if the buffers are too small the scatter pass did not run either (the counters
+		// are not list ends) -- every tile is reported empty, so that whatever is queued behind reads nothing, and the host starts over
+		if (ctl[0] > capacity)
+		{
+			if (n_lo == 0 && threadIdx.x == 0) ranges[tile] = make_uint2(0u, 0u);
+			return;
+		}
+		tile_sort_one<THREADS, ITEMS>(tile, list_end, pairs, point_list, ranges, big_scratch, n_lo, lds_cap, rank_max, last);
 	}
 
 	// ------------------------------------------------------------------------------------------------
@@ -670,18 +720,35 @@ namespace fdgs
 	void tile_sort_debug_limits(int lds_cap, int rank_max)
 	{
 		g_lds_cap.store(lds_cap > 0 && lds_cap < TS_LARGE ? lds_cap : TS_LARGE);
-		g_rank_max.store(rank_max > 0 ? min(rank_max, TS_PAD) : 96);
+		g_rank_max.store(rank_max > 0 ? min(rank_max, TS_PAD - 4) : 96);
 	}
 	int tile_sort_lds_cap() { return g_lds_cap.load(); }
 
-	template <int THREADS>
-	static void launch_sort_instance(const uint32_t* counters, int T, const uint2* pairs, uint32_t* point_list, uint2* ranges, u64* big,
+	template <int THREADS, int ITEMS = TS_ITEMS>
+	static hipError_t launch_sort_instance(const uint32_t* counters, int T, const uint2* pairs, uint32_t* point_list, uint2* ranges, u64* big,
 	                                 int n_lo, int cap, int rank_max, const uint32_t* ctl, uint32_t capacity, bool last, const uint32_t* order,
 	                                 hipStream_t stream)
 	{
 		const int band = div_up(T, NUM_XCDS_BIN);
-		hipLaunchKernelGGL((tile_sort_kernel<THREADS>), dim3(order ? band * NUM_XCDS_BIN : T), dim3(THREADS), (size_t)cap * 8 + TS_PAD * 4, stream, counters, pairs,
+		const size_t lds = (size_t)cap * 8 + TS_PAD * 4;
+		if (lds > 48 * 1024)
+		{
+			// more dynamic LDS than the default limit: raise it once per (instance, device)
+			static std::atomic<unsigned long long> attr_done{0};   // bit d: set on device d
+			int dev = 0;
+			hipError_t e = hipGetDevice(&dev);
+			if (e != hipSuccess) return e;
+			if (dev >= 64 || !((attr_done.load(std::memory_order_acquire) >> dev) & 1ull))
+			{
+				e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<THREADS, ITEMS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+				                        THREADS * ITEMS * 8 + TS_PAD * 4);
+				if (e != hipSuccess) return e;
+				if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
+			}
+		}
+		hipLaunchKernelGGL((tile_sort_kernel<THREADS, ITEMS>), dim3(order ? band * NUM_XCDS_BIN : T), dim3(THREADS), lds, stream, counters, pairs,
 		                   point_list, ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0, order, T, band);
+		return hipSuccess;
 	}
 
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
@@ -694,22 +761,42 @@ namespace fdgs
 		// The main instance takes every tile and is sized by the longest list: 128 threads per tile while no list
 		// exceeds 1024 entries, else 256 (up to 2048 entries; measured at C3, where a quarter of the lists are longer than
 		// 1024: one 256-thread launch 62 us, a 128-thread launch plus a 256-thread launch for the long ones 88 us).  Lists
-		// beyond 2048 are rare: a second launch with 512 threads per tile takes them, and those beyond lds_cap (4096)
-		// go through its global-scratch path.  An instance's LDS is sized by the longest list it takes, in 64-key
-		// steps (a short longest list = more tiles in flight per CU).
+		// beyond 2048 are rare on a uniform scene and the rule on a clustered one (a trained scene: most Gaussians on the
+		// subject; C3-clustered: 700 of 5440 tiles).  They are taken by up to two more instances, all in LDS: 512 threads x
+		// 8 keys for (2048, 4096], and for what is longer still 1024 threads x 8 keys while nothing exceeds 8192, else 1024 x
+		// 16 (up to 16384).  Every instance is a launch over all tiles whose workgroups leave at once when the list is not
+		// theirs (looping launches of a few hundred workgroups that walk the tile order from its long end were built and are
+		// slower: 146 against 99 us for the three launches on C3-clustered -- the loop costs the body 40-80 VGPRs).  Only what is
+		// longer than lds_cap (16384) still goes through the bitonic network in global scratch (91 rounds of global round trips
+		// for 8192 keys: it used to take everything beyond 4096 -- 0.33 ms for the sort on C3-clustered).  An instance's LDS is
+		// sized by the longest list it takes, in 64-key steps (a short longest list = more tiles in flight per CU).
 		const int longest_lds = min(max_count, lds_cap);
 		const int c1 = min(128 * TS_ITEMS, lds_cap), c2 = min(256 * TS_ITEMS, lds_cap), c3 = min(512 * TS_ITEMS, lds_cap);
+		const int c4 = min(1024 * TS_ITEMS, lds_cap), c5 = min(1024 * TS_ITEMS_LONG, lds_cap);
 		const auto lds_keys = [&](int c) { return min(c, max(64, div_up(longest_lds, 64) * 64)); };
 		const bool overflow = max_count > lds_cap;   // somebody has to take the global path
 		if (div_up(T, NUM_XCDS_BIN) >= (1 << 24)) tile_order = nullptr;   // no order was written (launch_tile_bin)
+		hipError_t e = hipSuccess;
 		if (max_count <= c1 || c2 == c1)
-			launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, tile_order, stream);
+			e = launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, tile_order, stream);
 		else
 		{
 			const bool second = max_count > c2 && c3 > c2;
-			launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, tile_order, stream);
-			if (second) launch_sort_instance<512>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c2, lds_keys(c3), rank_max, ctl, capacity, true, tile_order, stream);
+			const bool third = second && longest_lds > c3 && c4 > c3;
+			e = launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, tile_order, stream);
+			if (second && e == hipSuccess)
+				e = launch_sort_instance<512>(counters, T, p2, point_list, r2, (overflow && !third) ? big : nullptr, c2, lds_keys(c3), rank_max, ctl, capacity, !third, tile_order,
+				                              stream);
+			if (third && e == hipSuccess)
+			{
+				if (longest_lds <= c4 || c5 == c4)
+					e = launch_sort_instance<1024>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c3, lds_keys(c4), rank_max, ctl, capacity, true, tile_order, stream);
+				else
+					e = launch_sort_instance<1024, TS_ITEMS_LONG>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c3, lds_keys(c5), rank_max, ctl, capacity, true,
+					                                              tile_order, stream);
+			}
 		}
+		if (e != hipSuccess) return e;
 		return hipGetLastError();
 	}
 }

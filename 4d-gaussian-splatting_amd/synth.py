@@ -38,7 +38,7 @@ CONFIGS: Dict[str, SceneConfig] = {
     "C5": SceneConfig("C5", 2_000_000, 2704, 2028, 3, 0, 0.006, 1.0, True, 4, True),
     # not a BASELINE config -- a skewed variant of C3: trained scenes (configs/dynerf/*.yaml) concentrate their Gaussians on the
     # subject; 70 % of them in a box that projects onto 15 % of the image: tile lists five times the average there (thousands of
-    # entries, some beyond the 4096 the LDS sort takes), empty tiles elsewhere
+    # entries, some beyond 4096: the 1024-thread instance of the per-tile sort), empty tiles elsewhere
     "C3-clustered": SceneConfig("C3-clustered", 300_000, 1352, 1014, 3, 2, 0.015, 10.0, True, 4, False, 0.7),
     # not a BASELINE config -- a scaling probe: C3 with 4 x the Gaussians on 4 x the image area at the same footprint per
     # Gaussian (focal doubles with W, so s0 halves): every per-tile quantity equals C3's, every launch is 4 x larger --

@@ -291,7 +291,7 @@ int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
  * thread for a (device, W, H, P), debug mode, fdgs_set_run_ahead(0)), and with n = 1.25 R' + 4096 <= 2^31 - 1 when it runs
  * ahead (R' = num_rendered of the thread's previous call for the same (device, W, H, P)); a second request in the same call
  * follows if that was too small.  Either request grows by 8 bytes per instance (of n) in the rare case that a single tile's
- * list is longer than the LDS sort takes (4096 entries).  A caller that pre-sizes a binning arena either uses that bound
+ * list is longer than the LDS sort takes (16384 entries).  A caller that pre-sizes a binning arena either uses that bound
  * or switches the run-ahead off. */
 size_t fdgs_geometry_bytes(int32_t P);
 size_t fdgs_image_bytes(int32_t W, int32_t H);
@@ -343,7 +343,7 @@ int fdgs_debug_block_reaches(int32_t n, const float* tuples, uint8_t* out, void*
 int fdgs_debug_clock_sample(uint64_t* out5, double span_ms, void* stream);
 
 /* Test hook: lists longer than `lds_cap` entries take the global-scratch sort, tiles whose most crowded depth bucket
- * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (4096, 96).  Process-wide. */
+ * exceeds `rank_max` the LDS bitonic sort (tilebin.hip); values <= 0 restore the defaults (16384, 96).  Process-wide. */
 void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);
 
 /* Optional per-stage timing with HIP events recorded on the caller's stream (so the

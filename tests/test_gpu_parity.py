@@ -355,7 +355,7 @@ def test_c3_full_size_vs_oracle(tile_cull, gpu_device):
 @pytest.mark.parametrize("tile_cull", [False, True])
 def test_c3_clustered_full_size_vs_oracle(tile_cull, gpu_device):
     """A skewed C3 (fdgs.synth C3-clustered: 70 % of the 300 k Gaussians on 15 % of the image, the bench's `clustered` leg): 3.2 M
-    instances, 188 tile lists beyond the 4096 entries the LDS sort takes (global-scratch path), the longest 5485 -- forward lists bit
+    instances, 188 tile lists beyond 4096 entries (the 1024-thread instance of the LDS sort), the longest 5485 -- forward lists bit
     for bit (or, with tile_cull, instance by instance), pixels and all gradients against the oracle at the usual bar."""
     scene = synth.make_scene(synth.CONFIGS["C3-clustered"], seed=0)
     W, H = scene["W"], scene["H"]
@@ -488,25 +488,25 @@ def test_tile_sort_equal_and_clustered_depths(gpu_device):
 
 
 def test_tile_sort_long_lists(gpu_device):
-    """Few tiles, many Gaussians: lists of several thousand entries.  Covers the 256- and 512-thread instances of the LDS
-    sort (lists of up to 2048 / 4096 entries) and, unforced, the global-scratch path for the lists beyond 4096."""
-    seen = []
-    for P, W, H in ((40000, 96, 64), (30000, 128, 96)):
+    """Few tiles, many Gaussians: lists of several thousand entries.  The second sort launch takes every list beyond 2048 entries
+    with ONE instance chosen by the longest list of the view -- 512 threads x 8 keys (longest 3082), 1024 x 8 (6653), 1024 x 16
+    (11574), and 1024 x 16 plus, unforced, the global-scratch path for the four lists beyond the 16384 the LDS takes (18088)."""
+    longest = []
+    for P, W, H in ((30000, 128, 96), (40000, 96, 64), (70000, 96, 64), (110000, 96, 64)):
         scene = synth.make_scene(SC("v", P, W, H, 0, 0, 0.03, 1.0, True, 4, True), seed=15)
         hip, ref = _binning_vs_oracle(scene, gpu_device, "long lists %dx%d" % (W, H))
         n = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
-        seen += n.tolist()
-        rep = check_forward(hip, ref, "long lists %dx%d" % (W, H))
-        print("long lists %dx%d: longest %d" % (W, H, n.max()), rep)
-    seen = np.array(seen)
-    assert (seen > 4096).any() and ((seen > 2048) & (seen <= 4096)).any() and ((seen > 1024) & (seen <= 2048)).any()
+        longest.append(int(n.max()))
+        rep = check_forward(hip, ref, "long lists %d on %dx%d" % (P, W, H))
+        print("long lists %d on %dx%d: longest %d, %d lists beyond 2048" % (P, W, H, n.max(), int((n > 2048).sum())), rep)
+    assert 2048 < longest[0] <= 4096 < longest[1] <= 8192 < longest[2] <= 16384 < longest[3], longest
 
 
 def test_forward_run_ahead_matches_exact_path(gpu_device):
     """The forward enqueues scatter / sort / blend before the host knows num_rendered, with buffers sized by the thread's
     previous call for the same (device, W, H, P) (capi.hip "run-ahead"); debug mode takes the exact path (wait, then size).  A
     sequence of scenes of ONE size that makes every guess wrong in turn -- more instances than the capacity, longer lists than the
-    sort instances launched, lists that need the global scratch the buffer was sized without, then much smaller again -- must
+    sort instances launched, twice over, then much smaller again -- must
     give bit-identical results either way (the forward is deterministic: no float atomics)."""
     from fdgs import _capi
     cfg = SC("ra", 30011, 320, 240, 0, 0, 0.03, 1.0, True, 4, True)   # a P no other test uses: the first call has no guess
@@ -520,7 +520,7 @@ def test_forward_run_ahead_matches_exact_path(gpu_device):
     seq = [("a", 1.0, 0.25),    # small splats: R ~ 55 k
            ("b", 1.0, 1.0),     # R ~ 129 k: over the capacity guessed from a
            ("c", 0.5, 0.45),    # drawn towards the image centre: fewer instances, lists of ~2100 where ~980 were the longest
-           ("d", 0.3, 0.45),    # lists beyond 4096: the global scratch the buffer was sized without
+           ("d", 0.3, 0.45),    # lists beyond 4096: twice what the launched instances take
            ("e", 1.0, 0.15),    # small again: everything fits
            ("f", 1.0, 0.8),     # back up: over capacity
            ("g", 1.0, 0.8)]     # same sizes again: the guess fits

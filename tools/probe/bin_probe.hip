@@ -93,17 +93,17 @@ int main(int argc, char** argv)
 					CK(hipEventRecord(ev[0]));
 					CK(hipMemsetAsync(d_cnt, 0, (T + 4) * 4));
 					CK(hipEventRecord(ev[1]));
-					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<false>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, (const float*)nullptr, P, gx, T, rounds, d_cnt, (uint2*)nullptr, (const uint32_t*)nullptr, 0u);
-					else hipLaunchKernelGGL(tile_bin_direct_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, (const float*)nullptr, P, gx, d_cnt, (uint2*)nullptr, (const uint32_t*)nullptr, 0u);
+					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<false>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)std::max(T, 8 * ORDER_BUCKETS) * 4, 0, d_rect, (const float*)nullptr, P, gx, T, rounds, d_cnt, (uint2*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, (T + 7) / 8);
+					else hipLaunchKernelGGL(tile_bin_direct_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, (const float*)nullptr, P, gx, d_cnt, (uint2*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, T, (T + 7) / 8);
 					CK(hipEventRecord(ev[2]));
-					hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, 0, d_cnt, T, per_thread, d_ctl, (uint32_t*)nullptr, 0u);
+					hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, 0, d_cnt, T, per_thread, d_ctl, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
 					CK(hipEventRecord(ev[3]));
 					CK(hipMemcpy(ctl, d_ctl, 8, hipMemcpyDeviceToHost));
 					CK(hipEventRecord(ev[6]));
-					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<true>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)T * 4, 0, d_rect, d_depth, P, gx, T, rounds, d_cnt, d_pairs, (const uint32_t*)d_ctl, 0xFFFFFFFFu);
-					else hipLaunchKernelGGL(tile_bin_direct_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, d_depth, P, gx, d_cnt, d_pairs, (const uint32_t*)d_ctl, 0xFFFFFFFFu);
+					if (rounds) hipLaunchKernelGGL(tile_bin_lds_kernel<true>, dim3((P + batch - 1) / batch), dim3(1024), (size_t)std::max(T, 8 * ORDER_BUCKETS) * 4, 0, d_rect, d_depth, P, gx, T, rounds, d_cnt, d_pairs, (const uint32_t*)d_ctl, 0xFFFFFFFFu, (uint32_t*)nullptr, (T + 7) / 8);
+					else hipLaunchKernelGGL(tile_bin_direct_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, 0, d_rect, d_depth, P, gx, d_cnt, d_pairs, (const uint32_t*)d_ctl, 0xFFFFFFFFu, (uint32_t*)nullptr, T, (T + 7) / 8);
 					CK(hipEventRecord(ev[4]));
-					CK(launch_tile_sort(d_cnt, T, (int)ctl[1], (const uint32_t*)d_pairs, d_pl, (uint32_t*)d_ranges, d_big, (const uint32_t*)d_ctl, 0xFFFFFFFFu, 0));
+					CK(launch_tile_sort(d_cnt, T, (int)ctl[1], (const uint32_t*)d_pairs, d_pl, (uint32_t*)d_ranges, d_big, (const uint32_t*)d_ctl, 0xFFFFFFFFu, (const uint32_t*)nullptr, 0));
 					CK(hipEventRecord(ev[5]));
 					CK(hipDeviceSynchronize());
 					CK(hipGetLastError());
@@ -145,6 +145,17 @@ int main(int argc, char** argv)
 					double tot = 0;
 					for (int k = 0; k < 9; k++) { double a2 = 0; for (int t = 0; t < T; t++) a2 += tl[(size_t)t * 16 + k]; printf(" %s %.0f", nm[k], a2 / T); tot += a2 / T; }
 					printf(" | total %.0f\n", tot);
+					// the same for the tiles of every length class
+					for (int lo : { 0, 1024, 2048, 4096, 8192 })
+					{
+						const int hi = lo == 0 ? 1024 : 2 * lo;
+						double a3[9] = { 0 }; int cnt = 0;
+						for (int t = 0; t < T; t++) { const int n = (int)(rg[t].y - rg[t].x); if (n > lo && n <= hi) { cnt++; for (int k = 0; k < 9; k++) a3[k] += tl[(size_t)t * 16 + k]; } }
+						if (!cnt) continue;
+						printf("   lists (%d, %d]: %d tiles:", lo, hi, cnt);
+						double t3 = 0; for (int k = 0; k < 9; k++) { printf(" %s %.0f", nm[k], a3[k] / cnt); t3 += a3[k] / cnt; }
+						printf(" | total %.0f cycles\n", t3);
+					}
 				}
 #endif
 				printf("batch %4d lds_cap_limit %4d rank_max %2d | memset %.1f  count %.1f  scan %.1f  scatter %.1f  sort %.1f us | max list %u | %s (%zu bad)\n",
