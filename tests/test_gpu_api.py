@@ -565,7 +565,10 @@ def test_step_pipeline_lazy_equals_waiting_and_redoes_an_overflowing_step(gpu_de
         torch.cuda.synchronize()
         runs[lazy] = (m.flat.detach().clone(), losses, Rs, sp.lazy_redone)
     assert runs[False][3] == 0 and runs[True][3] == 1, (runs[False][3], runs[True][3])
-    assert runs[True][2] == runs[False][2] and min(runs[True][2]) > 0, (runs[True][2], runs[False][2])
+    # the first step starts from identical parameters: identical lists; later steps follow an Adam update whose float-atomics noise
+    # differs from run to run (a parameter may move by 2 lr): a handful of the ~14-37 k instances per view may come or go
+    assert runs[True][2][:B] == runs[False][2][:B] and min(runs[True][2]) > 0, (runs[True][2], runs[False][2])
+    assert all(abs(a - b) <= 1e-3 * b for a, b in zip(runs[True][2], runs[False][2])), (runs[True][2], runs[False][2])
     np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=1e-5, atol=1e-6)
     perr = (runs[True][0] - runs[False][0]).abs()
     assert (perr > 2e-3).float().mean().item() <= 2e-3 and perr.max().item() <= 0.25   # (Adam on float-atomics noise: see above)
