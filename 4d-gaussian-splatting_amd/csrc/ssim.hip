@@ -5,7 +5,7 @@
 // C1 = 0.01^2, C2 = 0.03^2, mean over all pixels and channels).  The reference runs it as five
 // grouped 11x11 convolutions forward plus their backward through the DL library; on ROCm that
 // is ~7.6 ms per 1352x1014 image, four times the whole rasterizer.  Here:
-//   forward : one pass.  A 32x16 output tile loads its 42x26 halo of both images into LDS as (x, y) pairs, does
+//   forward : one pass.  A 32x32 output tile loads its 42x42 halo of both images into LDS as (x, y) pairs, does
 //             the separable window (horizontal, then vertical) for the five moments
 //             (x, y, x^2, y^2, xy), evaluates SSIM and the three partial derivatives
 //             d ssim/d mu1, d ssim/d E[x^2], d ssim/d E[xy] per pixel (kept for the backward),
@@ -13,7 +13,10 @@
 //             The kernel is VALU-issue bound (SQ counters), so it is written for instruction count: the
 //             moments travel as pairs (x,y) (x^2,y^2) + xy -> three packed-fp32 FMAs per tap instead of five;
 //             a thread produces 4 adjacent outputs of the horizontal pass (14 b128-loaded inputs instead of
-//             44 scalar reads) and 2 of the vertical pass.
+//             44 scalar reads) and 4 adjacent rows of the vertical pass (14 row reads per 4 outputs).  Round 4: 32x32 tile
+//             instead of 32x16 (halo 1.72 x instead of 2.13 x the tile, 1.31 instead of 1.63 rows of horizontal pass per
+//             output row) with the input tile's LDS bytes reused for the filtered arrays: forward + backward 85.5 -> 76 us
+//             per 1352x1014 image.
 //   backward: dL/dx(p) = w_l1 sign(x-y) + w_ssim [ (W * dmu1)(p) + 2 x(p) (W * dE11)(p) + y(p) (W * dE12)(p) ]
 //             -- three more separable windows over the stored derivative maps (W symmetric).
 // fp32, ~200 VALU instructions per pixel-channel forward, ~100 backward; no MFMA (11-tap separable stencil).
@@ -21,7 +24,11 @@
 
 namespace fdgs
 {
-	constexpr int STX = 32, STY = 16;    // output tile
+#ifndef FDGS_SSIM_STY
+#define FDGS_SSIM_STY 32   // 16: the tile of rounds 1-3 (A/B: FDGS_EXTRA_FLAGS=-DFDGS_SSIM_STY=16 csrc/build.sh)
+#endif
+	constexpr int STX = 32, STY = FDGS_SSIM_STY;    // output tile (rows: 16 or 32)
+	constexpr int SROWS = STY / 8;       // adjacent output rows a thread finishes in the vertical pass (256 threads = 32 columns x 8 row groups)
 	constexpr int SR = 5;                // window radius (11 taps)
 	constexpr int SW = STX + 2 * SR;     // 42: tile + halo, columns
 	constexpr int SHH = STY + 2 * SR;    // 26: rows
@@ -50,10 +57,17 @@ namespace fdgs
 		float* __restrict__ dm_dmu1, float* __restrict__ dm_de11, float* __restrict__ dm_de12,
 		float* __restrict__ partial_l1, float* __restrict__ partial_ssim)
 	{
-		__shared__ __attribute__((aligned(16))) v2f s_in[SHH][SSTR];   // (x, y)
-		__shared__ __attribute__((aligned(16))) v2f h_m[SHH][HSTR];     // horizontally filtered (x, y)
-		__shared__ __attribute__((aligned(16))) v2f h_s[SHH][HSTR];     // (x^2, y^2)
-		__shared__ __attribute__((aligned(16))) float h_x[SHH][HSTR1F];  // x y
+		// The input tile shares its bytes with two of the three horizontally filtered arrays: those results wait in registers until
+		// every task of the horizontal pass has read its inputs (a barrier in between).  A workgroup then holds 34 KB instead of 49
+		// (32-row tile): four workgroups per CU instead of three.  (All three behind the barrier: 16 more VGPRs for nothing -- the
+		// results are larger than the inputs.)
+		constexpr int IN_BYTES = SHH * SSTR * 8, HM_BYTES = SHH * HSTR * 8, HX_BYTES = SHH * HSTR1F * 4;
+		constexpr int SH_BYTES = IN_BYTES > HM_BYTES + HX_BYTES ? IN_BYTES : HM_BYTES + HX_BYTES;
+		__shared__ __attribute__((aligned(16))) char s_raw[HM_BYTES + SH_BYTES];
+		v2f (*h_m)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw);                                   // horizontally filtered (x, y)
+		v2f (*s_in)[SSTR] = reinterpret_cast<v2f (*)[SSTR]>(s_raw + HM_BYTES);                       // (x, y)
+		v2f (*h_s)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw + HM_BYTES);                        // (x^2, y^2): over the input tile
+		float (*h_x)[HSTR1F] = reinterpret_cast<float (*)[HSTR1F]>(s_raw + 2 * HM_BYTES);            // x y: over the input tile
 		__shared__ float red[2][STHREADS / WAVE];
 
 		const int c = blockIdx.z;
@@ -61,68 +75,94 @@ namespace fdgs
 		const int tid = threadIdx.x;
 		const size_t plane = (size_t)c * H * W;
 
-		// halo element i = tid, tid + 256, ... -> (row, column).  All loads of the thread are issued before the first one is
-		// waited for (a rolled loop paid one global round trip per trip: 5 in a row)
+		// halo: thread -> one column of the 42 and rows tid / 42, + 6, + 12, ... (252 of the 256 threads; the column, its bounds test
+		// and the address are computed once, a trip only moves down six rows).  All loads of the thread are issued before the first
+		// one is waited for (a rolled loop paid one global round trip per trip)
+		float l1 = 0.f;   // |x - y| over the tile's own pixels: summed where they are loaded (the input tile is gone after the horizontal pass)
 		{
-			constexpr int TRIPS = (SHH * SW + STHREADS - 1) / STHREADS;
+			constexpr int RPT = STHREADS / SW, TRIPS = (SHH + RPT - 1) / RPT;
+			const int lyb = tid / SW, hx = tid - lyb * SW;
+			const int gxh = x0 + hx - SR;
+			const bool col_in = tid < RPT * SW && (unsigned)gxh < (unsigned)W;
+			const bool col_own = (unsigned)(hx - SR) < (unsigned)STX;
 			v2f p[TRIPS];
 #pragma unroll
 			for (int t = 0; t < TRIPS; t++)
 			{
-				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
-				const int gy = y0 + ly - SR, gx = x0 + lx - SR;
-				const bool in = i < SHH * SW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-				const size_t o = in ? plane + (size_t)gy * W + gx : plane;   // branch-free: outside lanes read a valid address
+				const int ly = lyb + t * RPT, gy = y0 + ly - SR;
+				const bool in = col_in && ly < SHH && (unsigned)gy < (unsigned)H;
+				const size_t o = in ? plane + (size_t)gy * W + gxh : plane;   // branch-free: outside lanes read a valid address
 				const float vx = img1[o], vy = img2[o];
 				p[t] = in ? v2f{ vx, vy } : v2f{ 0.0f, 0.0f };               // zero padding (F.conv2d padding = 5)
 			}
 #pragma unroll
 			for (int t = 0; t < TRIPS; t++)
 			{
-				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
-				if (i < SHH * SW) s_in[ly][lx] = p[t];
+				const int ly = lyb + t * RPT;
+				if (tid < RPT * SW && ly < SHH) s_in[ly][hx] = p[t];
+				const bool own = col_own && (unsigned)(ly - SR) < (unsigned)STY;   // (outside the image: 0 - 0)
+				l1 += own ? fabsf(p[t].x - p[t].y) : 0.0f;
 			}
 		}
 		__syncthreads();
 
-		// horizontal pass: thread -> (row, 4 adjacent columns)
-		if (tid < SHH * (STX / 4))
+		// horizontal pass: task -> (row, 4 adjacent columns); SHH * 8 tasks over the 256 threads in HR rounds; results stay in
+		// registers until every task has read its inputs
+		constexpr int HR = (SHH * (STX / 4) + STHREADS - 1) / STHREADS;
+		v2f as[HR][4];
+		float ax[HR][4];
+#pragma unroll
+		for (int r = 0; r < HR; r++)
 		{
-			const int ly = tid >> 3, cx = (tid & 7) * 4;
-			v2f p[16], sq[14];
-			float xy[14];
-			const v4f* src = reinterpret_cast<const v4f*>(&s_in[ly][cx]);
-#pragma unroll
-			for (int i = 0; i < 7; i++) { const v4f q = src[i]; p[2 * i] = v2f{ q.x, q.y }; p[2 * i + 1] = v2f{ q.z, q.w }; }
-#pragma unroll
-			for (int i = 0; i < 14; i++) { sq[i] = p[i] * p[i]; xy[i] = p[i].x * p[i].y; }
-			v2f am[4], as[4];
-			float ax[4];
-#pragma unroll
-			for (int j = 0; j < 4; j++)
+			const int task = tid + r * STHREADS;
+			if (task < SHH * (STX / 4))
 			{
-				am[j] = GW[0] * p[j]; as[j] = GW[0] * sq[j]; ax[j] = GW[0] * xy[j];
+				const int ly = task >> 3, cx = (task & 7) * 4;
+				v2f p[16], sq[14];
+				float xy[14];
+				const v4f* src = reinterpret_cast<const v4f*>(&s_in[ly][cx]);
 #pragma unroll
-				for (int k = 1; k < 11; k++) { am[j] += GW[k] * p[j + k]; as[j] += GW[k] * sq[j + k]; ax[j] += GW[k] * xy[j + k]; }
+				for (int i = 0; i < 7; i++) { const v4f q = src[i]; p[2 * i] = v2f{ q.x, q.y }; p[2 * i + 1] = v2f{ q.z, q.w }; }
+#pragma unroll
+				for (int i = 0; i < 14; i++) { sq[i] = p[i] * p[i]; xy[i] = p[i].x * p[i].y; }
+				v2f am[4];
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+				{
+					am[j] = GW[0] * p[j]; as[r][j] = GW[0] * sq[j]; ax[r][j] = GW[0] * xy[j];
+#pragma unroll
+					for (int k = 1; k < 11; k++) { am[j] += GW[k] * p[j + k]; as[r][j] += GW[k] * sq[j + k]; ax[r][j] += GW[k] * xy[j + k]; }
+				}
+				v4f* dm = reinterpret_cast<v4f*>(&h_m[ly][cx]);   // (its own bytes: written at once)
+				dm[0] = v4f{ am[0].x, am[0].y, am[1].x, am[1].y }; dm[1] = v4f{ am[2].x, am[2].y, am[3].x, am[3].y };
 			}
-			v4f* dm = reinterpret_cast<v4f*>(&h_m[ly][cx]);
-			v4f* ds = reinterpret_cast<v4f*>(&h_s[ly][cx]);
-			dm[0] = v4f{ am[0].x, am[0].y, am[1].x, am[1].y }; dm[1] = v4f{ am[2].x, am[2].y, am[3].x, am[3].y };
-			ds[0] = v4f{ as[0].x, as[0].y, as[1].x, as[1].y }; ds[1] = v4f{ as[2].x, as[2].y, as[3].x, as[3].y };
-			*reinterpret_cast<v4f*>(&h_x[ly][cx]) = v4f{ ax[0], ax[1], ax[2], ax[3] };
+			__builtin_amdgcn_sched_barrier(0);   // one round's inputs at a time in registers
+		}
+		__syncthreads();   // the input tile has been read: its bytes become the filtered arrays
+#pragma unroll
+		for (int r = 0; r < HR; r++)
+		{
+			const int task = tid + r * STHREADS;
+			if (task < SHH * (STX / 4))
+			{
+				const int ly = task >> 3, cx = (task & 7) * 4;
+				v4f* ds = reinterpret_cast<v4f*>(&h_s[ly][cx]);
+				ds[0] = v4f{ as[r][0].x, as[r][0].y, as[r][1].x, as[r][1].y }; ds[1] = v4f{ as[r][2].x, as[r][2].y, as[r][3].x, as[r][3].y };
+				*reinterpret_cast<v4f*>(&h_x[ly][cx]) = v4f{ ax[r][0], ax[r][1], ax[r][2], ax[r][3] };
+			}
 		}
 		__syncthreads();
 
-		// vertical pass: thread -> (column, 2 adjacent rows)
-		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * 2;
-		v2f vm[12], vs[12];
-		float vx[12];
+		// vertical pass: thread -> (column, SROWS adjacent rows)
+		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * SROWS;
+		v2f vm[10 + SROWS], vs[10 + SROWS];
+		float vx[10 + SROWS];
 #pragma unroll
-		for (int r = 0; r < 12; r++) { vm[r] = h_m[ly0 + r][lx]; vs[r] = h_s[ly0 + r][lx]; vx[r] = h_x[ly0 + r][lx]; }
-		float l1 = 0.f, sv = 0.f;
+		for (int r = 0; r < 10 + SROWS; r++) { vm[r] = h_m[ly0 + r][lx]; vs[r] = h_s[ly0 + r][lx]; vx[r] = h_x[ly0 + r][lx]; }
+		float sv = 0.f;
 		const int gx = x0 + lx;
 #pragma unroll
-		for (int j = 0; j < 2; j++)
+		for (int j = 0; j < SROWS; j++)
 		{
 			v2f mu = GW[0] * vm[j], e2 = GW[0] * vs[j];
 			float e12 = GW[0] * vx[j];
@@ -147,8 +187,6 @@ namespace fdgs
 				dm_de11[o] = dm_dD;
 				dm_de12[o] = 2.f * dm_dB;
 				sv += m;
-				const v2f ctr = s_in[ly0 + j + SR][lx + SR];
-				l1 += fabsf(ctr.x - ctr.y);
 			}
 		}
 		// per-tile partial sums (wave shuffle + 4 partials)
@@ -169,10 +207,14 @@ namespace fdgs
 		const float* __restrict__ dm_dmu1, const float* __restrict__ dm_de11, const float* __restrict__ dm_de12,
 		const float* __restrict__ upstream, float w_l1, float w_ssim, float* __restrict__ dL_dimg1)
 	{
-		__shared__ __attribute__((aligned(16))) v2f s_p[SHH][SSTR];    // (dm/dmu1, dm/dE11)
-		__shared__ __attribute__((aligned(16))) float s_q[SHH][SSTR1]; // dm/dE12
-		__shared__ __attribute__((aligned(16))) v2f h_p[SHH][HSTR];
-		__shared__ __attribute__((aligned(16))) float h_q[SHH][HSTR1B];
+		// (inputs and horizontally filtered maps share their bytes, as in the forward kernel)
+		constexpr int SP_BYTES = SHH * SSTR * 8, SQ_BYTES = SHH * SSTR1 * 4, HP_BYTES = SHH * HSTR * 8, HQ_BYTES = SHH * HSTR1B * 4;
+		constexpr int LDS_BYTES = SP_BYTES + SQ_BYTES > HP_BYTES + HQ_BYTES ? SP_BYTES + SQ_BYTES : HP_BYTES + HQ_BYTES;
+		__shared__ __attribute__((aligned(16))) char s_raw[LDS_BYTES];
+		v2f (*s_p)[SSTR] = reinterpret_cast<v2f (*)[SSTR]>(s_raw);                       // (dm/dmu1, dm/dE11)
+		float (*s_q)[SSTR1] = reinterpret_cast<float (*)[SSTR1]>(s_raw + SP_BYTES);      // dm/dE12
+		v2f (*h_p)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw);
+		float (*h_q)[HSTR1B] = reinterpret_cast<float (*)[HSTR1B]>(s_raw + HP_BYTES);
 
 		const int c = blockIdx.z;
 		const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
@@ -180,16 +222,18 @@ namespace fdgs
 		const size_t plane = (size_t)c * H * W;
 
 		{
-			constexpr int TRIPS = (SHH * SW + STHREADS - 1) / STHREADS;
+			constexpr int RPT = STHREADS / SW, TRIPS = (SHH + RPT - 1) / RPT;   // (thread -> column + every sixth row, as in the forward kernel)
+			const int lyb = tid / SW, hx = tid - lyb * SW;
+			const int gxh = x0 + hx - SR;
+			const bool col_in = tid < RPT * SW && (unsigned)gxh < (unsigned)W;
 			v2f p[TRIPS];
 			float q[TRIPS];
 #pragma unroll
 			for (int t = 0; t < TRIPS; t++)       // every load in flight before the first wait
 			{
-				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
-				const int gy = y0 + ly - SR, gx = x0 + lx - SR;
-				const bool in = i < SHH * SW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-				const size_t o = in ? plane + (size_t)gy * W + gx : plane;   // branch-free: outside lanes read a valid address
+				const int ly = lyb + t * RPT, gy = y0 + ly - SR;
+				const bool in = col_in && ly < SHH && (unsigned)gy < (unsigned)H;
+				const size_t o = in ? plane + (size_t)gy * W + gxh : plane;   // branch-free: outside lanes read a valid address
 				const float va = dm_dmu1[o], vb = dm_de11[o], vc = dm_de12[o];
 				p[t] = in ? v2f{ va, vb } : v2f{ 0.0f, 0.0f };
 				q[t] = in ? vc : 0.0f;
@@ -197,54 +241,71 @@ namespace fdgs
 #pragma unroll
 			for (int t = 0; t < TRIPS; t++)
 			{
-				const int i = tid + t * STHREADS, ly = i / SW, lx = i - ly * SW;
-				if (i < SHH * SW) { s_p[ly][lx] = p[t]; s_q[ly][lx] = q[t]; }
+				const int ly = lyb + t * RPT;
+				if (tid < RPT * SW && ly < SHH) { s_p[ly][hx] = p[t]; s_q[ly][hx] = q[t]; }
 			}
 		}
-		// the two pixels this thread finishes below: their image values travel while the windows are computed
-		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * 2;
+		// the pixels this thread finishes below: their image values travel while the windows are computed
+		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * SROWS;
 		const int gx = x0 + lx;
-		float px[2], py[2];
+		float px[SROWS], py[SROWS];
 #pragma unroll
-		for (int j = 0; j < 2; j++)
+		for (int j = 0; j < SROWS; j++)
 		{
 			const int gy = y0 + ly0 + j;
 			const size_t o = (gx < W && gy < H) ? plane + (size_t)gy * W + gx : plane;
 			px[j] = img1[o]; py[j] = img2[o];
 		}
 		__syncthreads();
-		if (tid < SHH * (STX / 4))
+		constexpr int HR = (SHH * (STX / 4) + STHREADS - 1) / STHREADS;
+		v2f ap[HR][4];
+		float aq[HR][4];
+#pragma unroll
+		for (int r = 0; r < HR; r++)
 		{
-			const int ly = tid >> 3, cx = (tid & 7) * 4;
-			v2f p[16];
-			float q[16];
-			const v4f* sp = reinterpret_cast<const v4f*>(&s_p[ly][cx]);
-			const v4f* sq = reinterpret_cast<const v4f*>(&s_q[ly][cx]);
-#pragma unroll
-			for (int i = 0; i < 7; i++) { const v4f t = sp[i]; p[2 * i] = v2f{ t.x, t.y }; p[2 * i + 1] = v2f{ t.z, t.w }; }
-#pragma unroll
-			for (int i = 0; i < 4; i++) { const v4f t = sq[i]; q[4 * i] = t.x; q[4 * i + 1] = t.y; q[4 * i + 2] = t.z; q[4 * i + 3] = t.w; }
-			v2f ap[4];
-			float aq[4];
-#pragma unroll
-			for (int j = 0; j < 4; j++)
+			const int task = tid + r * STHREADS;
+			if (task < SHH * (STX / 4))
 			{
-				ap[j] = GW[0] * p[j]; aq[j] = GW[0] * q[j];
+				const int ly = task >> 3, cx = (task & 7) * 4;
+				v2f p[16];
+				float q[16];
+				const v4f* sp = reinterpret_cast<const v4f*>(&s_p[ly][cx]);
+				const v4f* sq = reinterpret_cast<const v4f*>(&s_q[ly][cx]);
 #pragma unroll
-				for (int k = 1; k < 11; k++) { ap[j] += GW[k] * p[j + k]; aq[j] += GW[k] * q[j + k]; }
+				for (int i = 0; i < 7; i++) { const v4f t = sp[i]; p[2 * i] = v2f{ t.x, t.y }; p[2 * i + 1] = v2f{ t.z, t.w }; }
+#pragma unroll
+				for (int i = 0; i < 4; i++) { const v4f t = sq[i]; q[4 * i] = t.x; q[4 * i + 1] = t.y; q[4 * i + 2] = t.z; q[4 * i + 3] = t.w; }
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+				{
+					ap[r][j] = GW[0] * p[j]; aq[r][j] = GW[0] * q[j];
+#pragma unroll
+					for (int k = 1; k < 11; k++) { ap[r][j] += GW[k] * p[j + k]; aq[r][j] += GW[k] * q[j + k]; }
+				}
 			}
-			v4f* dp = reinterpret_cast<v4f*>(&h_p[ly][cx]);
-			dp[0] = v4f{ ap[0].x, ap[0].y, ap[1].x, ap[1].y }; dp[1] = v4f{ ap[2].x, ap[2].y, ap[3].x, ap[3].y };
-			*reinterpret_cast<v4f*>(&h_q[ly][cx]) = v4f{ aq[0], aq[1], aq[2], aq[3] };
+			__builtin_amdgcn_sched_barrier(0);   // one round's inputs at a time in registers
+		}
+		__syncthreads();   // the inputs have been read: their bytes become the filtered arrays
+#pragma unroll
+		for (int r = 0; r < HR; r++)
+		{
+			const int task = tid + r * STHREADS;
+			if (task < SHH * (STX / 4))
+			{
+				const int ly = task >> 3, cx = (task & 7) * 4;
+				v4f* dp = reinterpret_cast<v4f*>(&h_p[ly][cx]);
+				dp[0] = v4f{ ap[r][0].x, ap[r][0].y, ap[r][1].x, ap[r][1].y }; dp[1] = v4f{ ap[r][2].x, ap[r][2].y, ap[r][3].x, ap[r][3].y };
+				*reinterpret_cast<v4f*>(&h_q[ly][cx]) = v4f{ aq[r][0], aq[r][1], aq[r][2], aq[r][3] };
+			}
 		}
 		__syncthreads();
-		v2f vp[12];
-		float vq[12];
+		v2f vp[10 + SROWS];
+		float vq[10 + SROWS];
 #pragma unroll
-		for (int r = 0; r < 12; r++) { vp[r] = h_p[ly0 + r][lx]; vq[r] = h_q[ly0 + r][lx]; }
+		for (int r = 0; r < 10 + SROWS; r++) { vp[r] = h_p[ly0 + r][lx]; vq[r] = h_q[ly0 + r][lx]; }
 		const float up = upstream[0];
 #pragma unroll
-		for (int j = 0; j < 2; j++)
+		for (int j = 0; j < SROWS; j++)
 		{
 			v2f ab = GW[0] * vp[j];
 			float d = GW[0] * vq[j];
