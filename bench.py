@@ -438,11 +438,24 @@ def main():
     torch.cuda.synchronize(dev)
     tw = time.perf_counter()
     warm_steps = 0
-    while warm_steps < args.warmup or (time.perf_counter() - tw) * 1e3 < args.min_warmup_ms:
+    for _ in range(args.warmup):
         step()
         warm_steps += 1
-        if warm_steps >= args.warmup and warm_steps % 4 == 0:
-            torch.cuda.synchronize(dev)   # the host runs ahead of the device: measure time that has actually been worked
+    while args.min_warmup_ms > 0:
+        # every rank takes the same number of steps (a step holds collectives): the decision to go on is taken together, on time
+        # that has actually been worked (the host runs ahead of the device)
+        torch.cuda.synchronize(dev)
+        more = 1 if (time.perf_counter() - tw) * 1e3 < args.min_warmup_ms else 0
+        if world > 1:
+            import torch.distributed as dist
+            t_more = torch.tensor([more], dtype=torch.int64, device=dev)
+            dist.all_reduce(t_more, op=dist.ReduceOp.MAX)
+            more = int(t_more.item())
+        if not more:
+            break
+        for _ in range(4):
+            step()
+        warm_steps += 4
     torch.cuda.synchronize(dev)
     # Untimed stage pass on ONE stream (kernel time, not queueing time behind the other stream's launches): every
     # rasterizer stage bracketed with HIP events -> the per-stage table and the dominant stage.

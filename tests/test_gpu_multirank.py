@@ -46,7 +46,9 @@ def test_bench_launches_its_own_ranks(gpu_device):
     env = dict(os.environ, FDGS_BENCH_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup-ms", "0", "--min-timed-ms", "0", "--workload", "C2",
+    # time-based warm-up and a minimum timed duration, as the driver's flags leave them on: how many steps that makes is decided by
+    # the ranks TOGETHER (a step holds collectives: a rank that took one more would hang the others)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup-ms", "40", "--min-timed-ms", "60", "--workload", "C2",
            "--cpu-samples", "0", "--host-cost-steps", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -55,6 +57,7 @@ def test_bench_launches_its_own_ranks(gpu_device):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["replicas_identical"] is True
     assert d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert d["steps_timed"] >= 2 and d["steps_timed"] % 2 == 0 and d["warmup_steps_run"] >= 1
 
 
 def test_bench_refuses_more_ranks_than_gpus(gpu_device):
