@@ -268,7 +268,7 @@ namespace fdgs
 		const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
 		const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_masks,
 		const float* __restrict__ dL_dpix_flow,
-		float* __restrict__ gacc)
+		float* __restrict__ gacc, const uint32_t* __restrict__ ctl)
 	{
 		// Wave-private queue of the surviving entries of the current chunk, stored as PAIRS of entries interleaved word by
 		// word, as in blend_fwd.hip: (x0,x1,y0,y1) (A0,A1,B0,B1) (C0,C1,o0,o1) (r0,r1,g0,g1) (b0,b1,d0,d1) (fx0,fx1,fy0,fy1):
@@ -460,19 +460,30 @@ namespace fdgs
 			*reinterpret_cast<float2*>(acc_b + (off_pair + (uint32_t)pair_in_group * 512u)) = make_float2(ga[0], ga[1]);
 		};
 
-		for (int top = wave_last; top > 0; top -= WAVE)
+		// The forward's per-block cull is not run again: it left one bit per (list entry, block) in the binning buffer (BinLayout::
+		// cull_bits; stride and offset in ctl[2], ctl[3]), one 64-bit word per 64-entry chunk of the list -- the chunks taken here are
+		// the forward's (positions 64 c .. 64 c + 63), from the one that holds the block's deepest contributor downwards.  Every chunk
+		// up to that one was culled by the forward before it could stop.  (The test itself was 64 VALU instructions per chunk and two
+		// record words per entry, surviving or not.)  ctl[2] == 0: a forward without planes (P = 0).
+		const uint32_t cull_stride = ctl ? ctl[2] : 0u;
+		const unsigned long long* cull_words = nullptr;
+		if (cull_stride != 0u)
+			cull_words = reinterpret_cast<const unsigned long long*>(point_list) + ctl[3] + (size_t)blk.sub * cull_stride + (range.x >> 6) + (uint32_t)blk.tile;
+		for (int chunk = (wave_last - 1) >> 6; chunk >= 0; chunk--)
 		{
-			// this chunk covers list positions top-1 downto max(0, top-64); lane 0 takes the deepest one
-			const int pos = top - 1 - lane;
-			bool keep = false;
-			uint32_t id = 0;
+			// positions 64 chunk + 63 downto 64 chunk; lane 0 takes the deepest one
+			const int pos = chunk * WAVE + (WAVE - 1) - lane;
+			// (no planes: every entry is taken -- the cull only saves work, an entry it would drop contributes nothing)
+			// the ids of the whole chunk travel together with the plane word (one coalesced load, no dependency between the two); only
+			// the survivors' records are gathered
+			const uint32_t id = pos < wave_last ? point_list[range.x + (uint32_t)pos] : 0u;
+			const unsigned long long fw = cull_words != nullptr ? cull_words[chunk] : ~0ull;
+			const bool keep = pos < wave_last && ((fw >> (WAVE - 1 - lane)) & 1ull) != 0ull;
 			float4 a, b;
-			if (pos >= 0)
+			if (keep)
 			{
-				id = point_list[range.x + (uint32_t)pos];
 				a = record_word(records, id, 0);
 				b = record_word(records, id, 1);
-				keep = block_reaches(a, b, rx0, rx1, ry0, ry1);
 			}
 			const unsigned long long mask = __ballot(keep);
 			const int cnt = __popcll(mask);
@@ -557,8 +568,8 @@ namespace fdgs
 		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg, \
 		const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, \
 		const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_masks, \
-		const float* __restrict__ dL_dpix_flow, float* __restrict__ gacc
-#define FDGS_BWD_ARGS ranges, point_list, records, tile_order, W, H, grid_x, ntiles, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_masks, dL_dpix_flow, gacc
+		const float* __restrict__ dL_dpix_flow, float* __restrict__ gacc, const uint32_t* __restrict__ ctl
+#define FDGS_BWD_ARGS ranges, point_list, records, tile_order, W, H, grid_x, ntiles, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_masks, dL_dpix_flow, gacc, ctl
 	template <bool AUX> __global__ void __launch_bounds__(WAVE) blend_bwd_kernel(FDGS_BWD_PARAMS);
 	template <> __global__ void __launch_bounds__(WAVE) blend_bwd_kernel<false>(FDGS_BWD_PARAMS) { blend_bwd_body<false>(FDGS_BWD_ARGS); }
 	template <> __global__ void __launch_bounds__(WAVE) blend_bwd_kernel<true>(FDGS_BWD_PARAMS) { blend_bwd_body<true>(FDGS_BWD_ARGS); }
@@ -567,14 +578,14 @@ namespace fdgs
 
 	hipError_t launch_blend_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                            const float* records, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
-	                            const float* final_T, const uint32_t* n_contrib, hipStream_t stream)
+	                            const float* final_T, const uint32_t* n_contrib, const uint32_t* ctl, hipStream_t stream)
 	{
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
 		const int ntiles = gx * gy;
 #define LAUNCH_BWD(AUX) hipLaunchKernelGGL((blend_bwd_kernel<AUX>), dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream, \
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records), \
 		                   tile_order, s.W, s.H, gx, ntiles, s.bg, final_T, n_contrib, \
-		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow, out.grad_accum)
+		                   in.dL_dout_color, in.dL_dout_depth, in.dL_dout_alpha, in.dL_dout_flow, out.grad_accum, ctl)
 		if (s.P >= (1 << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets into the 64-byte accumulator records
 		if (in.dL_dout_depth || in.dL_dout_alpha || in.dL_dout_flow) LAUNCH_BWD(true);
 		else LAUNCH_BWD(false);

@@ -25,7 +25,9 @@ namespace fdgs
 		const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ records,
 		const uint32_t* __restrict__ tile_order, int W, int H, int grid_x, int ntiles, const float* __restrict__ bg,
 		float* __restrict__ out_color, float* __restrict__ out_flow, float* __restrict__ out_depth, float* __restrict__ out_T,
-		float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+		float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+		unsigned long long* __restrict__ cull_bits /* BinLayout::cull_bits or NULL */, uint32_t cull_stride, uint32_t cull_word_off,
+		uint32_t* __restrict__ ctl)
 	{
 		// Wave-private queue of the surviving entries of the current 64-entry chunk, stored as PAIRS of entries with the
 		// two entries interleaved word by word: (x0,x1,y0,y1) (A0,A1,B0,B1) (C0,C1,o0,o1) (r0,r1,g0,g1) (b0,b1,d0,d1)
@@ -36,9 +38,11 @@ namespace fdgs
 		// other rows, so the loop addresses the whole queue with one base register and immediate offsets
 		__shared__ float4 s_q[7][QP];
 
+		const int lane = threadIdx.x;
+		// where the backward finds the cull planes: stride and offset (64-bit words from the start of the binning buffer)
+		if (blockIdx.x == 0 && lane == 0 && ctl != nullptr) { ctl[2] = cull_bits ? cull_stride : 0u; ctl[3] = cull_word_off; }
 		const BlockId blk = block_of(blockIdx.x, ntiles, tile_order);
 		if (blk.tile >= ntiles) return;
-		const int lane = threadIdx.x;
 		const int bx0 = (blk.tile % grid_x) * TILE_X + (blk.sub & 1) * BLK;
 		const int by0 = (blk.tile / grid_x) * TILE_Y + (blk.sub >> 1) * BLK;
 		if (bx0 >= W || by0 >= H) return; // block entirely outside the image
@@ -73,6 +77,9 @@ namespace fdgs
 			}
 			const unsigned long long mask = __ballot(keep);
 			const int cnt = __popcll(mask);
+			// kept for the backward (bit i = list position base + i): it takes the same 64-entry chunks and skips the test
+			if (cull_bits != nullptr && lane == 0)
+				cull_bits[(size_t)blk.sub * cull_stride + (range.x >> 6) + (uint32_t)blk.tile + (uint32_t)(base >> 6)] = mask;
 			if (keep)
 			{
 				const int slot = __popcll(mask & lt_mask);
@@ -165,7 +172,8 @@ namespace fdgs
 
 	hipError_t launch_blend_fwd(const fdgs_scene& s, const fdgs_forward_out& out, const float* records,
 	                            const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
-	                            float* final_T, uint32_t* n_contrib, hipStream_t stream)
+	                            float* final_T, uint32_t* n_contrib, unsigned long long* cull_bits, uint32_t cull_stride, uint32_t cull_word_off,
+	                            uint32_t* ctl, hipStream_t stream)
 	{
 		const int gx = div_up(s.W, TILE_X), gy = div_up(s.H, TILE_Y);
 		const int ntiles = gx * gy;
@@ -173,7 +181,7 @@ namespace fdgs
 #define LAUNCH_FWD(FLOW) hipLaunchKernelGGL(blend_fwd_kernel<FLOW>, dim3(blend_grid(ntiles)), dim3(WAVE), 0, stream, \
 		                   reinterpret_cast<const uint2*>(ranges), point_list, reinterpret_cast<const float4*>(records), \
 		                   tile_order, s.W, s.H, gx, ntiles, s.bg, \
-		                   out.out_color, out.out_flow, out.out_depth, out.out_T, final_T, n_contrib)
+		                   out.out_color, out.out_flow, out.out_depth, out.out_T, final_T, n_contrib, cull_bits, cull_stride, cull_word_off, ctl)
 		if (s.flows != nullptr) LAUNCH_FWD(true);
 		else LAUNCH_FWD(false);
 #undef LAUNCH_FWD

@@ -168,7 +168,10 @@ static int check_scene(const fdgs_scene* s)
 
 extern "C" size_t fdgs_geometry_bytes(int32_t P) { return geom_layout(P).total; }
 extern "C" size_t fdgs_image_bytes(int32_t W, int32_t H) { return image_layout(W, H).total; }
-extern "C" size_t fdgs_binning_bytes(int32_t R, int32_t, int32_t) { return bin_layout(R, false).total; }
+extern "C" size_t fdgs_binning_bytes(int32_t R, int32_t W, int32_t H)
+{
+	return bin_layout(R, false, div_up(W > 0 ? W : 1, TILE_X) * div_up(H > 0 ? H : 1, TILE_Y)).total;
+}
 extern "C" void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max) { tile_sort_debug_limits(lds_cap, rank_max); }
 extern "C" const char* fdgs_last_error(void) { return g_err; }
 extern "C" int fdgs_version(void) { return FDGS_VERSION; }
@@ -315,9 +318,9 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	if (P == 0)
 	{
 		// nothing to bin; the blend kernel still writes background colour / T = 1 everywhere
-		if (!alloc(alloc_user, FDGS_BUF_BINNING, bin_layout(0, false).total)) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+		if (!alloc(alloc_user, FDGS_BUF_BINNING, bin_layout(0, false, T).total)) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
 		STAGE(FDGS_STAGE_TILE_SORT, hipMemsetAsync(ranges, 0, (size_t)T * 8, stream), "ranges memset");
-		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, nullptr, ranges, nullptr, final_T, n_contrib, stream), "blend_fwd");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, nullptr, ranges, nullptr, final_T, n_contrib, nullptr, 0u, 0u, ctl, stream), "blend_fwd");
 		return FDGS_OK;
 	}
 
@@ -429,7 +432,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		ahead_longest = lmax + lmax / 2 + 64;
 	}
 	char* bin = nullptr;
-	BinLayout BL = bin_layout(0, false);
+	BinLayout BL = bin_layout(0, false, T);
 	bool has_scratch = false;   // BL includes the global sort scratch
 	const auto enqueue_rest = [&](long long capacity, int sort_longest, bool scatter) -> int
 	{
@@ -440,13 +443,14 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, sort_longest, pairs, point_list, ranges,
 		                       has_scratch ? (void*)(bin + BL.big_scratch) : nullptr, ctl, (uint32_t)capacity, tile_order, stream), "tile sort");
 		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
-		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, stream), "blend_fwd");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, (unsigned long long*)(bin + BL.cull_bits),
+		                                                   BL.cull_stride, (uint32_t)(BL.cull_bits / 8), ctl, stream), "blend_fwd");
 		return FDGS_OK;
 	};
 	if (ahead)
 	{
 		has_scratch = ahead_longest > lds_cap;
-		BL = bin_layout((int)ahead_cap, has_scratch);
+		BL = bin_layout((int)ahead_cap, has_scratch, T);
 		bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
 		if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
 		if ((rc = enqueue_rest(ahead_cap, ahead_longest, true)) != FDGS_OK) return rc;
@@ -493,13 +497,14 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		if (extra) HIP_TRY(hipFreeAsync(extra, stream), "hipFreeAsync (sort scratch)");   // stream-ordered: after the sort, whether it was launched or not
 		HIP_TRY(sorted, "tile sort");
 		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
-		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, stream), "blend_fwd");
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, (unsigned long long*)(bin + BL.cull_bits),
+		                                                   BL.cull_stride, (uint32_t)(BL.cull_bits / 8), ctl, stream), "blend_fwd");
 		return FDGS_OK;
 	}
 	// first call of this thread, debug mode, or more instances than guessed (nothing was scattered): exact sizes
 	g_run_ahead[2]++;
 	has_scratch = longest > lds_cap;
-	BL = bin_layout(R, has_scratch);
+	BL = bin_layout(R, has_scratch, T);
 	bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
 	if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
 	return enqueue_rest(R, longest, true);
@@ -535,7 +540,7 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	const int R = in->num_rendered;   // < 0: not known (a lazy forward): the tile ranges carry everything the kernels need
 	const GeomLayout GL = geom_layout(P);
 	const ImageLayout IL = image_layout(W, H);
-	const BinLayout BL = bin_layout(R, false);   // point_list sits at the front whatever else the forward asked for
+	const BinLayout BL = bin_layout(R, false, 0);   // point_list sits at the front whatever else the forward asked for (the cull planes: ctl[2..3])
 	const char* geom = (const char*)in->geom_buffer;
 	const char* img = (const char*)in->image_buffer;
 	const char* bin = (const char*)in->binning_buffer;
@@ -556,7 +561,8 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 			STAGE(FDGS_STAGE_GRAD_ZERO, hipMemsetAsync(out->grad_accum, 0, (size_t)P * GRAD_ACC_WORDS * 4, stream), "memset");
 		if (R != 0)
 			STAGE(FDGS_STAGE_BLEND_BWD, launch_blend_bwd(s, *in, *out, (const float*)(geom + GL.records), point_list, (const uint32_t*)(img + IL.ranges),
-			                       bwd_order ? (const uint32_t*)(img + IL.tile_order) : nullptr, (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib), stream), "blend_bwd");
+			                       bwd_order ? (const uint32_t*)(img + IL.tile_order) : nullptr, (const float*)(img + IL.final_T), (const uint32_t*)(img + IL.n_contrib),
+			                       (const uint32_t*)(img + IL.bin_ctl), stream), "blend_bwd");
 		if (!(out->stage_mask & 4)) STAGE(FDGS_STAGE_SH_BWD, launch_sh_bwd(s, *in, *out, geom, stream), "sh_bwd");
 	}
 	if (stages & 2)
@@ -718,7 +724,7 @@ extern "C" int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t R,
 	CHECK_STRUCT(v, fdgs_debug_view);
 	const GeomLayout GL = geom_layout(P);
 	const ImageLayout IL = image_layout(W, H);
-	const BinLayout BL = bin_layout(R, false);
+	const BinLayout BL = bin_layout(R, false, 0);
 	const char* geom = (const char*)geom_v;
 	const char* bin = (const char*)bin_v;
 	const char* img = (const char*)img_v;

@@ -87,14 +87,21 @@ namespace fdgs
 	// scatter pass, and -- only when some tile's list is longer than the LDS sort takes -- R keys of global scratch.
 	struct BinLayout
 	{
-		size_t point_list, pairs, big_scratch, total;
+		size_t point_list, cull_bits, pairs, big_scratch, total;
+		uint32_t cull_stride;   // 64-bit words per sub-block plane of cull_bits
 	};
-	static inline BinLayout bin_layout(int R, bool with_big_scratch)
+	// cull_bits: what the blend forward's per-block cull decided, one bit per (list entry, 8x8 block), kept for the blend backward
+	// (which used to run the same test again: a tenth of its instructions).  Four planes (one per sub-block of a tile) of
+	// cull_stride 64-bit words; the 64 entries [64 c, 64 c + 64) of tile t's list sit in word (list start >> 6) + t + c of the
+	// plane -- consecutive tiles never share a word (the + t), and the index stays below (R >> 6) + T + 1.
+	static inline BinLayout bin_layout(int R, bool with_big_scratch, int T)
 	{
 		BinLayout L;
 		size_t o = 0;
 		const size_t r = (size_t)(R > 0 ? R : 1);
 		L.point_list = o; o = align_up(o + r * 4);
+		L.cull_stride = (uint32_t)((r >> 6) + (size_t)(T > 0 ? T : 0) + 2);
+		L.cull_bits = o; o = align_up(o + (size_t)L.cull_stride * 4 * 8);
 		L.pairs = o; o = align_up(o + r * 8);
 		L.big_scratch = o;
 		if (with_big_scratch) o = align_up(o + r * 8);
@@ -135,13 +142,17 @@ namespace fdgs
 	void tile_sort_debug_limits(int lds_cap, int rank_max);    // test hook (fdgs_debug_tile_sort_limits); <= 0 restores the default
 
 	// tile_order: NULL = tiles in index order
+	// cull_bits / cull_stride (BinLayout; NULL: not kept) and ctl (the image buffer's control words): the forward leaves the plane
+	// stride in ctl[2] and the plane array's offset from the start of the binning buffer (in 64-bit words) in ctl[3] for the backward
 	hipError_t launch_blend_fwd(const fdgs_scene& s, const fdgs_forward_out& out, const float* records,
 	                            const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
-	                            float* final_T, uint32_t* n_contrib, hipStream_t stream);
+	                            float* final_T, uint32_t* n_contrib, unsigned long long* cull_bits, uint32_t cull_stride, uint32_t cull_word_off,
+	                            uint32_t* ctl, hipStream_t stream);
 
 	hipError_t launch_blend_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                            const float* records, const uint32_t* point_list, const uint32_t* ranges, const uint32_t* tile_order,
-	                            const float* final_T, const uint32_t* n_contrib, hipStream_t stream);
+	                            const float* final_T, const uint32_t* n_contrib, const uint32_t* ctl /* cull planes: see launch_blend_fwd */,
+	                            hipStream_t stream);
 
 	// SH / 4D-SH backward (coalesced); must run after the blend backward and before launch_preprocess_bwd
 	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
