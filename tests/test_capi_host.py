@@ -37,7 +37,12 @@ def test_scratch_sizes_are_monotone_and_aligned():
     i = _capi.lib.fdgs_image_bytes(1352, 1014)
     assert i % 256 == 0 and i >= 1352 * 1014 * 8
     b = _capi.lib.fdgs_binning_bytes(3_000_000, 1352, 1014)
-    assert b % 256 == 0 and 12 * 3_000_000 <= b < 13 * 3_000_000  # point_list 4 B + (depth bits, id) pairs 8 B per instance
+    assert b % 256 == 0 and 12 * 3_000_000 <= b < 13 * 3_000_000  # point_list 4 B + (depth bits, id) pairs 8 B per instance + cull planes
+    # the cull planes (one bit per list entry and 8x8 block + one word per tile and plane): 4 x (R / 64 + T + 2) 64-bit words
+    T = ((1352 + 15) // 16) * ((1014 + 15) // 16)
+    assert b >= 12 * 3_000_000 + 32 * (3_000_000 // 64 + T + 2)
+    small = _capi.lib.fdgs_binning_bytes(10, 1352, 1014)   # few instances on many tiles: the per-tile words dominate
+    assert small >= 32 * (T + 2) and small < 64 * (T + 2) + 4096
 
 
 def test_argument_errors_are_reported_without_touching_the_gpu():
