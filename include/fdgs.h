@@ -291,7 +291,8 @@ int fdgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
  * thread for a (device, W, H, P), debug mode, fdgs_set_run_ahead(0)), and with n = 1.25 R' + 4096 <= 2^31 - 1 when it runs
  * ahead (R' = num_rendered of the thread's previous call for the same (device, W, H, P)); a second request in the same call
  * follows if that was too small.  Either request grows by 8 bytes per instance (of n) in the rare case that a single tile's
- * list is longer than the LDS sort takes (16384 entries).  A caller that pre-sizes a binning arena either uses that bound
+ * list is longer than the LDS sort takes (16384 entries).  (fdgs_binning_bytes(n) = 12 bytes per instance + 32 bytes per 64
+ * instances and per tile: the blend forward's per-block cull decisions, kept for the blend backward.)  A caller that pre-sizes a binning arena either uses that bound
  * or switches the run-ahead off. */
 size_t fdgs_geometry_bytes(int32_t P);
 size_t fdgs_image_bytes(int32_t W, int32_t H);
