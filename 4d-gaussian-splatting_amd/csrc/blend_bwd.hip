@@ -287,8 +287,6 @@ namespace fdgs
 		const int px = bx0 + (lane & (BLK - 1)), py = by0 + (lane >> 3);
 		const bool inside = px < W && py < H;
 		const float pixfx = (float)px, pixfy = (float)py;
-		const float rx0 = (float)bx0, rx1 = (float)min(bx0 + BLK - 1, W - 1);
-		const float ry0 = (float)by0, ry1 = (float)min(by0 + BLK - 1, H - 1);
 		const size_t pix_id = (size_t)W * py + px, HW = (size_t)H * W;
 		const uint2 range = ranges[blk.tile];
 		const unsigned long long lt_mask = (1ull << lane) - 1ull;
