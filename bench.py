@@ -36,6 +36,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Several ranks: the step's own streams (caller's, forward, backward, the clock sampler) already fill the runtime's default of 4
+# hardware queues, and RCCL brings streams of its own; streams that share a hardware queue give steps that take several times as
+# long now and then (measured on one GPU with a third stream in the step: DESIGN.md section 5a).  One rank stays on the default (8
+# queues cost the two-stream step 1 %).  Must be set before the HIP runtime starts; inherited by the ranks a self-launch starts.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or any(a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1] not in ("1", "0")
+                                                      for i, a in enumerate(sys.argv)) or any(a.startswith("--gpus=") and a[7:] not in ("1", "0") for a in sys.argv):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -831,6 +838,7 @@ def main():
         "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4),
         "ms_per_image": round(dt / (steps_timed * B) * 1e3, 4),
         "lazy_forward": bool(use_pipeline and not args.no_lazy and world == 1), "lazy_steps_redone": lazy_redone,
+        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,
         "dtype": "f32", "data": "synthetic",
