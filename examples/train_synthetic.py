@@ -8,6 +8,10 @@ Uses fdgs.harness.train (FrameShard + StepPipeline + one gradient all-reduce per
 """
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # the step's own streams fill the runtime's default of 4 hardware queues; RCCL adds its own
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch
 
 
