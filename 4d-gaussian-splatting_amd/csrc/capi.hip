@@ -193,7 +193,7 @@ namespace
 {
 	constexpr int MAIL_SLOTS = 64;   // forwards of one thread that may be unreported at a time (fdgs_forward_out.lazy); 16 bytes each
 	struct RunAhead { int dev = -1, W = 0, H = 0, P = 0; long long capacity = 0; int longest = 0; long long r_hist[4] = { 0, 0, 0, 0 }; int l_hist[4] = { 0, 0, 0, 0 }; int hist_at = 0; };
-	struct MailRec { unsigned long long seq = 0; long long cap = 0; int longest_cap = 0; RunAhead* guess = nullptr; int gdev = 0, gW = 0, gH = 0, gP = 0; bool pending = false, lazy = false; };
+	struct MailRec { unsigned long long seq = 0; long long cap = 0; int longest_cap = 0; RunAhead* guess = nullptr; int gdev = 0, gW = 0, gH = 0, gP = 0; bool pending = false, lazy = false; hipStream_t stream = nullptr; /* the stream the forward (its tile scan) was enqueued on */ };
 	struct Mailbox
 	{
 		volatile uint32_t* host = nullptr; uint32_t* dev = nullptr;
@@ -216,10 +216,12 @@ namespace
 	// Reads the reports of this thread's pending forwards, oldest first, up to sequence number `upto` (inclusive; HARVEST_ALL: every
 	// forward handed a number so far -- only where all of them are REGISTERED, i.e. not between ++box.seq and the registration of
 	// that forward's record: the loop would step over the unregistered number and the forward's own wait would find nothing to
-	// wait for).  wait: block until they are in; otherwise stop at the first one that has not reported.  stream (optional): polled
-	// now and then while waiting, so that a failed launch ends the wait.  Returns false when a report never showed up.
+	// wait for).  wait: block until they are in; otherwise stop at the first one that has not reported.  While waiting, the stream
+	// the PENDING forward itself was enqueued on (MailRec::stream -- not the caller's: a lazy forward may have gone onto another
+	// stream than the call that reads its report) is polled now and then: once it has drained (or failed) the report is in or
+	// never will be -- one look after a device-wide synchronize decides.  Returns false when a report never showed up.
 	constexpr unsigned long long HARVEST_ALL = ~0ull;
-	bool harvest(Mailbox& box, bool wait, unsigned long long upto, hipStream_t stream, bool have_stream)
+	bool harvest(Mailbox& box, bool wait, unsigned long long upto)
 	{
 		while (box.head <= box.seq && box.head <= upto)
 		{
@@ -229,12 +231,13 @@ namespace
 			const uint32_t want = ticket_of(r.seq);
 			bool arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want;
 			if (!arrived && !wait) return true;
-			for (long spin = 0; !arrived && spin < 2000000000L; spin++)   // bounded: tens of seconds
+			for (unsigned long long spin = 0; !arrived; spin++)
 			{
 				arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want;
-				if (!arrived && have_stream && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(stream) != hipErrorNotReady)
+				if (!arrived && (spin & 0xFFFF) == 0xFFFF && hipStreamQuery(r.stream) != hipErrorNotReady)
 				{
 					arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want;
+					if (!arrived) { (void)hipDeviceSynchronize(); arrived = __atomic_load_n(&m[2], __ATOMIC_ACQUIRE) == want; }
 					break;
 				}
 			}
@@ -268,7 +271,8 @@ extern "C" int fdgs_forward_lazy_status(int32_t wait, void* stream_v, int32_t* p
 		return FDGS_OK;
 	}
 	Mailbox& box = *g_box_of[dev_id];
-	if (box.host && !harvest(box, wait != 0, HARVEST_ALL, (hipStream_t)stream_v, stream_v != nullptr))
+	(void)stream_v;   // (kept in the signature: every pending forward is waited for on ITS stream)
+	if (box.host && !harvest(box, wait != 0, HARVEST_ALL))
 		return fail(FDGS_ERR_HIP, "a lazy forward never reported num_rendered (failed launch?)");
 	int left = 0;
 	for (unsigned long long q = box.head; q <= box.seq; q++) if (box.rec[q % MAIL_SLOTS].pending && box.rec[q % MAIL_SLOTS].seq == q) left++;
@@ -384,11 +388,11 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		box.host = (volatile uint32_t*)h; box.dev = (uint32_t*)d;
 	}
 	// reports that are in by now refresh the guesses; the slot this call takes must be free (at most MAIL_SLOTS unreported forwards)
-	if (!harvest(box, false, HARVEST_ALL, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
+	if (!harvest(box, false, HARVEST_ALL)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
 	const unsigned long long seq = ++box.seq;
 	// (from here to the registration of this call's record below, box.seq counts a forward that has no record yet: harvest only up
 	// to older numbers)
-	if (seq > MAIL_SLOTS && !harvest(box, true, seq - MAIL_SLOTS, stream, true)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
+	if (seq > MAIL_SLOTS && !harvest(box, true, seq - MAIL_SLOTS)) return fail(FDGS_ERR_HIP, "a previous forward did not report num_rendered");
 	const int slot = (int)(seq % MAIL_SLOTS);
 	const uint32_t ticket = ticket_of(seq);
 	volatile uint32_t* const mail = box.host + 4 * slot;
@@ -415,7 +419,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	RunAhead& guess = *gp;
 	MailRec& rec = box.rec[slot];
 	rec = MailRec();
-	rec.seq = seq; rec.guess = gp; rec.gdev = dev_id; rec.gW = W; rec.gH = H; rec.gP = P; rec.pending = true;
+	rec.seq = seq; rec.guess = gp; rec.gdev = dev_id; rec.gW = W; rec.gH = H; rec.gP = P; rec.pending = true; rec.stream = stream;
 	const int lds_cap = tile_sort_lds_cap();
 	const bool ahead = guess.capacity > 0 && !debug && g_run_ahead_enabled.load(std::memory_order_relaxed);
 	// lazy: nobody is there to start over, so the headroom is generous -- 1.5 x the largest of the last four reports (+ 64 Ki
@@ -465,11 +469,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		return FDGS_OK;
 	}
 	// this call's own report (older pending ones -- lazy forwards -- are read on the way)
-	if (!harvest(box, true, seq, stream, true))
-	{
-		HIP_TRY(hipStreamSynchronize(stream), "num_rendered sync");
-		if (!harvest(box, true, seq, stream, false)) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered");
-	}
+	if (!harvest(box, true, seq)) return fail(FDGS_ERR_HIP, "the tile scan did not report num_rendered (failed launch?)");
 	if (rec.pending || __atomic_load_n(&mail[2], __ATOMIC_ACQUIRE) != ticket) return fail(FDGS_ERR_HIP, "internal: the forward's own report was not read");
 	const int R = (int)mail[0], longest = (int)mail[1];
 	if (R < 0) return fail(FDGS_ERR_INVALID_ARG, "num_rendered overflow");

@@ -55,6 +55,12 @@ class _RasterizeModel(torch.autograd.Function):
         if g_color is None and g_depth is None and g_alpha is None and g_flow is None:
             g_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=xyz.device)
         sunk = opt is not None and opt.is_homed() and opt.features().data_ptr() == feats.data_ptr()
+        if opt is not None and not sunk:
+            # the forward was handed the optimizer's bucket views (plain tensors, no requires_grad): returning gradients for them
+            # would be dropped by autograd without a word and no parameter would receive anything
+            raise RuntimeError("fdgs render(): the optimizer's parameters or Adam state were replaced between this view's forward and its "
+                               "backward (densification / prune / load_state_dict); the gradients of this view have nowhere to go -- "
+                               "run backward() before editing the optimizer, as the reference's loop does (train.py:160-249)")
         if sunk:
             sink, accumulate, gacc, stage = opt.backward_begin(rs)
             grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, ctx.prefilter_var,

@@ -24,6 +24,11 @@ working and changes what happens underneath:
 * **step** -- one fused HIP launch over the bucket (``fdgs_adam_step``; ``torch.optim.Adam`` arithmetic: no amsgrad, no weight
   decay) with the groups' CURRENT ``lr`` (``update_learning_rate`` keeps working), instead of 9 x ~12 small kernels.
 
+**Parameters whose ``grad`` is ``None`` at ``step()``**: ``torch.optim.Adam`` skips them.  Here the nine homed tensors are stepped
+together as soon as ANY of them received a gradient since the gradients were last cleared; one that received none is stepped with a
+zero gradient (its moments decay, it moves on them) -- the state the reference's loop is in anyway, where every backward reaches
+all nine.  If ALL of them are ``None`` (cleared by ``zero_grad()`` or by hand, no backward since) nothing is stepped, as in torch.
+
 Anything else in ``param_groups`` (a group without one of the nine names) is stepped tensor by tensor with the same kernel.
 Gradients that reach a parameter through plain autograd (another loss term, the Python-SH branch of ``render()``) are absorbed:
 ``p.grad`` is the bucket view, so autograd adds into it in place.
@@ -98,7 +103,9 @@ class Adam(torch.optim.Optimizer):
             if grp is None or grp["params"][0] is not p or p.data_ptr() != dptr:
                 return False
             st = self.state.get(p)
-            if not st or st["exp_avg"].data_ptr() != aptr or st["exp_avg_sq"].data_ptr() != sptr:
+            if not st or st.get("exp_avg") is None or st.get("exp_avg_sq") is None:   # (a state that holds only "step": not homed)
+                return False
+            if st["exp_avg"].data_ptr() != aptr or st["exp_avg_sq"].data_ptr() != sptr:
                 return False
         return len([n for n in g if n in _GEOMETRY or n in ("f_dc", "f_rest")]) == len(self._homed)
 
@@ -169,7 +176,7 @@ class Adam(torch.optim.Optimizer):
         self._features = feat[0]
         self._gacc = torch.zeros((P, 16), dtype=torch.float32, device=dev)
         if self._stages is not None and (self._stages.shape[1] != P or self._stages.device != dev):
-            # the Gaussians changed: staged views of the old layout cannot be applied (the reference densifies right after step())
+            # the Gaussians changed: staged views of the old layout cannot be applied (the reference densifies between backward() and step(), train.py:239-249: every parameter is replaced, none has a gradient, and torch.optim.Adam skips the step too)
             self._stages, self._n_staged = None, 0
         self._fresh = all(v is None for v in old_grad.values())
         self._dense_sh = old_grad.get("f_dc") is not None or old_grad.get("f_rest") is not None
@@ -195,6 +202,7 @@ class Adam(torch.optim.Optimizer):
         v = self._views
         g = self._named()
         grads = {n: g[n]["params"][0].grad for n in v}
+        self._note_cleared(grads)
         foreign = [n for n, pg in grads.items() if pg is not None and pg.data_ptr() != v[n][1].data_ptr()]
         if foreign:
             # gradients autograd produced on its own since zero_grad() (another loss term, a render() branch outside the fast path):
@@ -247,6 +255,16 @@ class Adam(torch.optim.Optimizer):
         self._fresh = False
         return sink, accumulate, self._gacc, stage
 
+    def _note_cleared(self, grads):
+        """Gradients cleared WITHOUT ``zero_grad()`` (``p.grad = None`` per parameter, a model-level helper): after a backward of
+        this step at least the geometry tensors' ``.grad`` are the bucket views, so "every homed parameter has ``grad is None``" can
+        only mean that the loop threw the last step's gradients away -- the bucket's contents and the staged views are stale, the
+        next backward has to OVERWRITE (as after ``zero_grad(set_to_none=True)``), not add."""
+        if not self._fresh and all(pg is None for pg in grads.values()):
+            self._fresh = True
+            self._dense_sh = False
+            self._n_staged = 0
+
     def note_forward(self, lazy: bool):
         if lazy:
             self._lazy_views += 1
@@ -259,7 +277,16 @@ class Adam(torch.optim.Optimizer):
             from .gaussian_renderer.diff_gaussian_rasterization import analytic_sh_gradients
             fv = self._gp.params["_features"].grad
             g = self._named()
-            have = g["f_dc"]["params"][0].grad is not None or g["f_rest"]["params"][0].grad is not None
+            gdc, grest = g["f_dc"]["params"][0].grad, g["f_rest"]["params"][0].grad
+            have = gdc is not None or grest is not None
+            if have:
+                # only ONE of f_dc / f_rest carries a dense gradient: the other half of the [P, M, 3] bucket view still holds an
+                # earlier step's values -- the flush below ADDS into the whole array, so that half has to start from zero
+                # (torch.optim.Adam would see "no gradient yet" there, then the staged views' sum)
+                if gdc is None:
+                    self._views["f_dc"][1].zero_()
+                if grest is None:
+                    self._views["f_rest"][1].zero_()
             _capi.sh_flush(self._stages[:self._n_staged], fv, ss.sh_degree, ss.sh_degree_t, ss.gaussian_dim, ss.force_sh_3d,
                            analytic_sh_gradients(), accumulate=have)
             for gname in ("f_dc", "f_rest"):
@@ -316,6 +343,7 @@ class Adam(torch.optim.Optimizer):
                     self._n_staged = 0
                     return False
             v = self._views
+            self._note_cleared({n: g[n]["params"][0].grad for n in v})   # cleared by hand since the last backward: nothing to step
             # autograd-made gradients the fast path has not seen (no render() backward since they appeared)
             for gname in v:
                 p = g[gname]["params"][0]

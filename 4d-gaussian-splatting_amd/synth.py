@@ -56,27 +56,55 @@ def num_sh_coeffs(sh_degree: int, sh_degree_t: int, force_sh_3d: bool, gaussian_
 
 
 def make_camera(W: int, H: int, focal: float = None, cam_z: float = -4.0,
-                znear: float = 0.01, zfar: float = 100.0) -> Dict[str, object]:
-    """Camera at (0,0,cam_z) looking down +z.
+                znear: float = 0.01, zfar: float = 100.0, yaw: float = 0.0, pitch: float = 0.0, roll: float = 0.0,
+                shift=(0.0, 0.0, 0.0), principal=None) -> Dict[str, object]:
+    """Pinhole camera.  Default: at (0,0,cam_z) looking down +z, no rotation.
 
-    Returns the tensors exactly as the reference Camera holds them
-    (scene/cameras.py:65-71): world_view_transform and full_proj_transform are
-    the transposes of the mathematical (column-vector) matrices.
+    ``yaw`` / ``pitch`` / ``roll`` (radians; camera-to-world R = Rz(roll) Rx(pitch) Ry(yaw), the ``R`` scene/cameras.py:65 receives)
+    and ``shift`` (added to the camera centre, world units) give a general pose: the camera is first placed at (0,0,cam_z)+shift and
+    then turned about its own centre, so every entry of the view matrix and 12 of the 16 of the full projection are non-zero.
+    ``principal`` = (cx, cy) in pixels selects the reference's centre-shift projection (utils/graphics_utils.py:74-91, taken when
+    the dataset carries cx / cy: scene/cameras.py:66-67), which fills the third column of the projection.
+
+    Returns the tensors exactly as the reference Camera holds them (scene/cameras.py:65-71): world_view_transform =
+    getWorld2View2(R, T).T (utils/graphics_utils.py:39-51), full_proj_transform = world_view_transform @ projection.T and
+    camera_center = inverse(world_view_transform)[3, :3] -- the transposes of the mathematical (column-vector) matrices.
     """
     if focal is None:
         focal = 0.9 * W
     tanfovx = W / (2.0 * focal)
     tanfovy = H / (2.0 * focal)
-    # world -> view, R = I, t = -C  (utils/graphics_utils.py:38-50)
+    cy_, sy_ = math.cos(yaw), math.sin(yaw)
+    cp_, sp_ = math.cos(pitch), math.sin(pitch)
+    cr_, sr_ = math.cos(roll), math.sin(roll)
+    Ry = np.array([[cy_, 0.0, sy_], [0.0, 1.0, 0.0], [-sy_, 0.0, cy_]])
+    Rx = np.array([[1.0, 0.0, 0.0], [0.0, cp_, -sp_], [0.0, sp_, cp_]])
+    Rz = np.array([[cr_, -sr_, 0.0], [sr_, cr_, 0.0], [0.0, 0.0, 1.0]])
+    R = Rz @ Rx @ Ry                                      # camera-to-world rotation
+    centre = np.array([0.0, 0.0, cam_z]) + np.asarray(shift, dtype=np.float64)
+    # world -> view: x_view = R^T (x - centre)  (utils/graphics_utils.py:39-51 with T = -R^T centre)
     Rt = np.eye(4, dtype=np.float64)
-    Rt[2, 3] = -cam_z
+    Rt[:3, :3] = R.T
+    Rt[:3, 3] = -R.T @ centre
     V = torch.tensor(np.float32(Rt))
-    # perspective (utils/graphics_utils.py:52-72)
-    top = tanfovy * znear
-    right = tanfovx * znear
     Pm = torch.zeros(4, 4)
-    Pm[0, 0] = 2.0 * znear / (2.0 * right)
-    Pm[1, 1] = 2.0 * znear / (2.0 * top)
+    if principal is None:
+        # perspective (utils/graphics_utils.py:52-72)
+        top = tanfovy * znear
+        right = tanfovx * znear
+        Pm[0, 0] = 2.0 * znear / (2.0 * right)
+        Pm[1, 1] = 2.0 * znear / (2.0 * top)
+    else:
+        # centre-shift perspective (utils/graphics_utils.py:74-91)
+        cx, cy = float(principal[0]), float(principal[1])
+        top = cy / focal * znear
+        bottom = -(H - cy) / focal * znear
+        left = -(W - cx) / focal * znear
+        right = cx / focal * znear
+        Pm[0, 0] = 2.0 * znear / (right - left)
+        Pm[1, 1] = 2.0 * znear / (top - bottom)
+        Pm[0, 2] = (right + left) / (right - left)
+        Pm[1, 2] = (top + bottom) / (top - bottom)
     Pm[3, 2] = 1.0
     Pm[2, 2] = zfar / (zfar - znear)
     Pm[2, 3] = -(zfar * znear) / (zfar - znear)
@@ -93,9 +121,39 @@ def make_camera(W: int, H: int, focal: float = None, cam_z: float = -4.0,
     }
 
 
+# General poses (yaw, pitch, roll in radians, shift in world units, principal-point offset in pixels from the image centre or None)
+# used by the parity tests, the golden fixtures and the bench: a DyNeRF rig (configs/dynerf/*.yaml) is ~20 cameras on an arc around
+# the subject, each turned towards it; "slant" is steep enough that Gaussians cross the 1.3 tanfov clamp (forward.cu:206-211) and the
+# z <= 0.2 cull plane (auxiliary.h:153) at an angle.
+POSES: Dict[str, dict] = {
+    "axis": dict(),
+    "rig0": dict(yaw=0.22, pitch=-0.09, roll=0.05, shift=(-0.9, 0.35, 0.2)),
+    "rig1": dict(yaw=-0.17, pitch=0.12, roll=-0.08, shift=(0.7, -0.45, -0.3)),
+    "rig2": dict(yaw=0.10, pitch=0.07, roll=0.03, shift=(-0.4, -0.3, 0.1), principal_off=(13.5, -9.25)),
+    "rig3": dict(yaw=-0.26, pitch=-0.05, roll=0.11, shift=(1.0, 0.2, 0.4)),
+    "slant": dict(yaw=0.55, pitch=0.40, roll=0.3, shift=(-1.1, 0.9, 2.7)),   # centre (-1.1, 0.9, -1.3): at the corner of the volume
+}
+
+
+def camera_for(pose, W: int, H: int) -> Dict[str, object]:
+    """make_camera for a POSES name or a pose dict."""
+    kw = dict(POSES[pose] if isinstance(pose, str) else pose)
+    off = kw.pop("principal_off", None)
+    if off is not None:
+        kw["principal"] = (0.5 * W + off[0], 0.5 * H + off[1])
+    return make_camera(W, H, **kw)
+
+
 def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H: int = None,
-               random_flow: bool = False, bg=(0.0, 0.0, 0.0), timestamp_frac: float = 0.5) -> Dict[str, object]:
+               random_flow: bool = False, bg=(0.0, 0.0, 0.0), timestamp_frac: float = 0.5, pose="axis",
+               alloc=None) -> Dict[str, object]:
     """Post-activation rasterizer inputs for ``cfg`` (CPU float32 tensors).
+
+    ``pose``: a POSES name or a make_camera keyword dict (default: the unrotated on-axis camera).
+    ``alloc`` = (D, D_t): allocate the SH coefficients of THAT degree pair (the reference always allocates its maximum,
+    scene/gaussian_model.py:65,92,222-228: M = 48 for (3, 2)) while the ACTIVE degrees stay cfg.sh_degree / cfg.sh_degree_t -- the
+    state of the first 5000 iterations of every training run (one degree up every 1000 iterations, gaussian_model.py:253-257,
+    train.py:93-94).  The coefficients beyond the active ones are non-zero on purpose: the kernels must not read them.
 
     Keys mirror GaussianRasterizer.forward's arguments
     (gaussian_renderer/diff_gaussian_rasterization.py:263-267) plus the settings.
@@ -127,11 +185,15 @@ def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H:
     rot = torch.nn.functional.normalize(ident + 0.05 * randn(P, 4), dim=1)
     rot_r = torch.nn.functional.normalize(ident + 0.05 * randn(P, 4), dim=1)
     opacity = torch.sigmoid(randn(P, 1))
-    M = num_sh_coeffs(cfg.sh_degree, cfg.sh_degree_t, cfg.force_sh_3d, cfg.gaussian_dim)
+    if alloc is None:
+        M = num_sh_coeffs(cfg.sh_degree, cfg.sh_degree_t, cfg.force_sh_3d, cfg.gaussian_dim)
+    else:
+        assert alloc[0] >= cfg.sh_degree and alloc[1] >= cfg.sh_degree_t, "allocated degrees below the active ones"
+        M = num_sh_coeffs(alloc[0], alloc[1], cfg.force_sh_3d, cfg.gaussian_dim)
     shs = 0.2 * randn(P, M, 3)
     shs[:, 0, :] = rand(P, 3) * 2.0 - 1.0
     flow = 0.5 * randn(P, 2) if random_flow else torch.zeros(P, 2)
-    cam = make_camera(W, H)
+    cam = camera_for(pose, W, H)
     scene = {
         "cfg": cfg, "P": P, "W": W, "H": H, "M": M,
         "means3D": xyz.contiguous(), "ts": ts.contiguous(),
@@ -141,12 +203,23 @@ def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H:
         "flow_2d": flow.contiguous(),
         "bg": torch.tensor(bg, dtype=torch.float32),
         "sh_degree": cfg.sh_degree, "sh_degree_t": cfg.sh_degree_t,
+        "max_sh_degree": cfg.sh_degree if alloc is None else int(alloc[0]),
+        "max_sh_degree_t": cfg.sh_degree_t if alloc is None else int(alloc[1]),
         "timestamp": float(timestamp_frac * dur), "time_duration": float(dur),
         "rot_4d": cfg.rot_4d, "gaussian_dim": cfg.gaussian_dim, "force_sh_3d": cfg.force_sh_3d,
         "scale_modifier": 1.0, "prefilter_var": -1.0,
     }
     scene.update(cam)
     return scene
+
+
+def active_sh_coeffs(sh_degree: int, sh_degree_t: int, force_sh_3d: bool, gaussian_dim: int) -> int:
+    """How many leading coefficients the kernels READ (and write gradients for) at the ACTIVE degrees: (D+1)^2 for 3D SH; for 4D SH
+    the time blocks only exist on top of a complete degree-3 spatial block (forward.cu:142: the time terms sit inside ``deg > 2``),
+    16 coefficients each."""
+    if gaussian_dim == 4 and not force_sh_3d and sh_degree > 2 and sh_degree_t > 0:
+        return 16 * (sh_degree_t + 1)
+    return (sh_degree + 1) ** 2
 
 
 def make_upstream_grads(W: int, H: int, seed: int = 1, scale: float = 1.0) -> Dict[str, torch.Tensor]:

@@ -58,12 +58,13 @@ class GaussianParams:
         with torch.no_grad():
             for name in self.NAMES:
                 self.params[name].copy_(init[name].to(device).reshape(shapes[name]))
-        # the coefficient storage (M) is laid out for these maxima; a model built from a scene starts with all of them active
-        # (a trained model); training from scratch starts at (0, 0) and ramps with oneupSHdegree() (harness.train)
-        self.max_sh_degree = int(scene["sh_degree"])
-        self.max_sh_degree_t = int(scene["sh_degree_t"])
-        self.active_sh_degree = self.max_sh_degree
-        self.active_sh_degree_t = self.max_sh_degree_t
+        # the coefficient storage (M) is laid out for these maxima (scene["max_sh_degree*"]: synth.make_scene(alloc=...), the
+        # reference's state from iteration 0: scene/gaussian_model.py:65,92); a model built from a scene starts at the scene's ACTIVE
+        # degrees -- all of them for a trained model; training from scratch starts at (0, 0) and ramps with oneupSHdegree()
+        self.max_sh_degree = int(scene.get("max_sh_degree", scene["sh_degree"]))
+        self.max_sh_degree_t = int(scene.get("max_sh_degree_t", scene["sh_degree_t"]))
+        self.active_sh_degree = int(scene["sh_degree"])
+        self.active_sh_degree_t = int(scene["sh_degree_t"])
         self.time_duration = [0.0, float(scene["time_duration"])]
         self.rot_4d, self.gaussian_dim = bool(scene["rot_4d"]), int(scene["gaussian_dim"])
         self.force_sh_3d = bool(scene["force_sh_3d"])

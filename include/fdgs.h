@@ -236,7 +236,8 @@ int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forward_out* out,
 
 /* The lazy forwards (fdgs_forward_out.lazy) of the CALLING THREAD on the current device, since the previous call of this function:
  * *pending = how many have not reported yet (always 0 with wait != 0: the call then blocks until the tile scan of the most recent one
- * has run -- `stream`, optional, is polled meanwhile so that a failed launch ends the wait); *failed = how many turned out not to fit
+ * has run -- every pending forward is waited for on the stream IT was enqueued on, whatever stream this call is made from: once that
+ * stream has drained or failed the report is in or the call fails; `stream` is accepted for compatibility and not used); *failed = how many turned out not to fit
  * their buffers: the outputs of those forwards are invalid and must be rendered again with lazy = 0; num_rendered[0 .. *n_out) = the
  * num_rendered of the reported ones, oldest first (at most max_out, at most 64).  Every pointer may be NULL. */
 int fdgs_forward_lazy_status(int32_t wait, void* stream, int32_t* pending, int32_t* failed,

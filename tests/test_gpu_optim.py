@@ -194,3 +194,90 @@ def test_fdgs_adam_foreign_groups_and_autograd_gradients(gpu_device):
     for a, b in zip(vals["fdgs"][1:], vals["torch"][1:]):
         perr = (a - b).abs()
         assert (perr > 2e-3).float().mean().item() <= 5e-3 and perr.max().item() <= 0.25
+
+
+def test_fdgs_adam_when_the_loop_clears_gradients_by_hand(gpu_device):
+    """Gradients cleared WITHOUT optimizer.zero_grad() -- ``p.grad = None`` per parameter (what ``zero_grad(set_to_none=True)`` does,
+    done by a model-level helper instead): the next backward must OVERWRITE the gradient bucket and drop the staged SH views of the
+    last iteration, not accumulate on top of them.  Same trajectory as torch.optim.Adam in the same loop."""
+    from fdgs.gaussian_renderer import render
+    from fdgs.loss import fused_l1_ssim
+    runs = {}
+    for which, defer in (("torch", None), ("fdgs", True), ("fdgs", False)):
+        scene, model, cams, gts, pipe, bg = _setup(gpu_device, which)
+        if which == "fdgs":
+            model.optimizer.defer_sh = defer
+        losses, gnorm = [], []
+        for it in range(4):
+            for b in range(len(cams)):
+                loss = fused_l1_ssim(render(cams[b], model, pipe, bg)["render"], gts[b], 0.2)
+                (loss / len(cams)).backward()
+                losses.append(float(loss))
+            gnorm.append(float(model._xyz.grad.abs().sum()))
+            model.optimizer.step()
+            for n in _names(model):
+                getattr(model, n).grad = None
+        torch.cuda.synchronize()
+        runs[(which, defer)] = (losses, gnorm, {n: getattr(model, n).detach().clone() for n in _names(model)})
+    want = runs[("torch", None)]
+    for key in (("fdgs", True), ("fdgs", False)):
+        np.testing.assert_allclose(runs[key][0], want[0], rtol=3e-5, atol=3e-6, err_msg=str(key))
+        # (a bucket that kept accumulating would show a gradient norm growing iteration after iteration)
+        np.testing.assert_allclose(runs[key][1], want[1], rtol=2e-3, err_msg=str(key))
+        for n, w in want[2].items():
+            perr = (runs[key][2][n] - w).abs()
+            assert (perr > 2e-3).float().mean().item() <= 5e-3 and perr.max().item() <= 0.25, (key, n, (perr > 2e-3).float().mean().item())
+
+
+def test_optimizer_edits_between_backward_and_step(gpu_device):
+    """The reference densifies, prunes and resets the opacities BETWEEN backward() and optimizer.step() (train.py:160-249).  The
+    replaced nn.Parameters have no gradient, so torch.optim.Adam skips them in that step: all nine after a prune / densification, the
+    opacity alone after reset_opacity.  fdgs.optim.Adam re-homes inside step() with live gradients and staged SH views: it must end
+    up with the same parameters."""
+    from fdgs.gaussian_renderer import render
+    from fdgs.loss import fused_l1_ssim
+    results = {}
+    for which in ("torch", "fdgs"):
+        scene, model, cams, gts, pipe, bg = _setup(gpu_device, which)
+
+        def backward_views():
+            for b in range(len(cams)):
+                (fused_l1_ssim(render(cams[b], model, pipe, bg)["render"], gts[b], 0.2) / len(cams)).backward()
+
+        def finish():
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=True)
+
+        backward_views(); finish()
+        # (1) opacity reset only (train.py:243-245 at opacity_reset_interval): every other tensor keeps its gradient and is stepped
+        backward_views()
+        before = {n: getattr(model, n).detach().clone() for n in _names(model)}
+        model.replace_tensor_to_optimizer(torch.full_like(model._opacity.detach(), -2.0), "opacity")
+        finish()
+        torch.cuda.synchronize()
+        assert float((model._opacity.detach() + 2.0).abs().max()) == 0.0, which            # no gradient, zero moments: not moved
+        assert float((model._xyz.detach() - before["_xyz"]).abs().max()) > 0.0, which       # the others were stepped
+        assert float((model._features_rest.detach() - before["_features_rest"]).abs().max()) > 0.0, which
+        # (2) prune + densify (train.py:239-241): every parameter is replaced, nothing has a gradient, nothing moves in this step
+        backward_views()
+        P = model._xyz.shape[0]
+        g = torch.Generator(device="cpu").manual_seed(3)
+        mask = (torch.rand(P, generator=g) < 0.2).to(gpu_device)
+        model.prune_points(mask)
+        sel = torch.arange(0, 300, device=gpu_device)
+        model.densification_postfix({name: getattr(model, attr).detach()[sel].clone() for name, attr in model._ATTR.items()
+                                     if any(grp["name"] == name for grp in model.optimizer.param_groups)})
+        edited = {n: getattr(model, n).detach().clone() for n in _names(model)}
+        finish()
+        torch.cuda.synchronize()
+        for n in _names(model):
+            assert torch.equal(getattr(model, n).detach(), edited[n]), (which, n)
+        # (3) training goes on
+        backward_views(); finish()
+        backward_views(); finish()
+        torch.cuda.synchronize()
+        results[which] = {n: getattr(model, n).detach().clone() for n in _names(model)}
+    for n, want in results["torch"].items():
+        perr = (results["fdgs"][n] - want).abs()
+        assert perr.shape == want.shape
+        assert (perr > 2e-3).float().mean().item() <= 5e-3 and perr.max().item() <= 0.25, (n, (perr > 2e-3).float().mean().item(), perr.max().item())

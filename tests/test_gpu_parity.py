@@ -156,7 +156,7 @@ def test_depth_only_backward_vs_oracle(gpu_device):
 # The configuration the metric is quoted on, through the path bench.py times
 # ----------------------------------------------------------------------------------------------------------------
 
-def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, scale_modifier=1.0, prefilter_var=-1.0):
+def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, scale_modifier=1.0, prefilter_var=-1.0, poses=None, alloc=None):
     """The calls fdgs/pipeline.py::StepPipeline makes for one optimizer step -- raw parameters (activations fused into
     the kernels, fdgs_scene.raw_params = 1), fused L1 + SSIM gradient as the only upstream gradient (colour-only blend
     backward), parameter gradients accumulated over the views into the flat bucket, persistent always-zero blend
@@ -180,7 +180,8 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, 
     pipe = train_host.PipelineFlags()
     bg = scene["bg"].to(dev)
     dur = scene["time_duration"]
-    cams = [train_host.SyntheticCamera(scene, dev, timestamp=(b + 0.5) / n_views * dur) for b in range(n_views)]
+    cam_tensors = [synth.camera_for(poses[b] if poses else "axis", W, H) for b in range(n_views)]
+    cams = [train_host.SyntheticCamera(dict(scene, **cam_tensors[b]), dev, timestamp=(b + 0.5) / n_views * dur) for b in range(n_views)]
     gen = torch.Generator(device="cpu").manual_seed(99)
     gts = [torch.rand(3, H, W, generator=gen).to(dev) for _ in range(n_views)]
     # The loss is a mean over 3 N pixels: its image gradient is O(1 / (3 N)).  The kernels are linear in the upstream
@@ -221,7 +222,7 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, 
         (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = res
         hip = collect_forward(res, P, W, H)
         g_color, _handle = l1_ssim_grad(color, gts[b], 0.2, up)
-        osc = dict(scene)
+        osc = dict(scene, **cam_tensors[b])
         osc.update(opacities=a_op, scales=a_sc, scales_t=a_sct, rotations=a_rot, rotations_r=a_rotr, timestamp=cam.timestamp,
                    scale_modifier=scale_modifier, prefilter_var=prefilter_var)
         o = pyoracle.Oracle(osc, kind="port")
@@ -289,6 +290,10 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, 
         total_f64 = r64 if total_f64 is None else {k: total_f64[k] + r64[k] for k in r64}
 
     got = {n: model.params[n].grad.detach().cpu().numpy() for n in model.NAMES}
+    n_active = synth.active_sh_coeffs(cfg.sh_degree, cfg.sh_degree_t, cfg.force_sh_3d, cfg.gaussian_dim)
+    assert float(np.abs(total["_features"].reshape(P, -1, 3)[:, n_active:]).max(initial=0.0)) == 0.0   # the reference's zeros
+    assert float(np.abs(got["_features"][:, n_active:]).max(initial=0.0)) == 0.0, "%s: a coefficient beyond the %d active ones received a gradient" % (label, n_active)
+    assert float(np.abs(got["_features"][:, :n_active]).max()) > 0.0
     line, just = {}, {}
     # Gradients of the covariance parameters are cancelling sums of products of dL/dcov3D (O(1e3) here) with the
     # scale / rotation matrices: the chain amplifies a 1e-6 relative rounding difference in the blend backward's per-Gaussian

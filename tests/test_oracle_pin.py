@@ -49,9 +49,12 @@ def test_port_equals_verbatim_reference_with_flags(name, mod, pv):
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("seed", [21, 22])
-def test_port_equals_verbatim_reference(name, seed, scale_modifier=1.0, prefilter_var=-1.0):
-    cfg, kw = CASES[name]
-    scene = synth.make_scene(cfg, seed=seed, **kw)
+def test_port_equals_verbatim_reference(name, seed, scale_modifier=1.0, prefilter_var=-1.0, make_kw=None, cfg=None):
+    if cfg is None:
+        cfg, kw = CASES[name]
+    else:
+        kw = {}
+    scene = synth.make_scene(cfg, seed=seed, **dict(kw, **(make_kw or {})))
     scene["scale_modifier"], scene["prefilter_var"] = scale_modifier, prefilter_var
     up = synth.make_upstream_grads(scene["W"], scene["H"], seed=seed + 100, scale=1e-2)
     ref, refg = run_oracle(scene, up, kind="reference")
@@ -78,8 +81,26 @@ def test_port_equals_verbatim_reference(name, seed, scale_modifier=1.0, prefilte
         assert err <= 2e-5 * scale, "%s %s: %g (scale %g)" % (name, k, err, scale)
 
 
-def test_mark_visible_matches():
-    scene = synth.make_scene(SC("p", 500, 64, 64, 0, 0, 0.03, 1.0, True, 4, True), seed=3)
+# General camera poses (fdgs.synth.POSES: rotation + off-axis centre, one with the centre-shift projection, one steep enough that
+# Gaussians cross the 1.3 tanfov clamp and the z <= 0.2 plane on a slant) -- forward.cu:198-237, backward.cu:486-617, 878-894 with every
+# matrix entry live -- and ACTIVE SH degrees below the allocated coefficient count (scene/gaussian_model.py:65,92,253-257: M = 48
+# allocated from iteration 0, the degrees step up every 1000 iterations; forward.cu:73-195, backward.cu:144-481 with stride != used).
+@pytest.mark.parametrize("pose", [p for p in synth.POSES if p != "axis"])
+@pytest.mark.parametrize("name", ["rot4d_sh3t2", "dim3_sh3", "dim4_norot_sh0"])
+def test_port_equals_verbatim_reference_on_general_cameras(name, pose):
+    test_port_equals_verbatim_reference(name, 24, make_kw=dict(pose=pose))
+
+
+@pytest.mark.parametrize("pose", ["axis", "rig1"])
+@pytest.mark.parametrize("deg", [(0, 0), (1, 0), (2, 0), (3, 0), (3, 1)])
+def test_port_equals_verbatim_reference_below_allocated_degree(deg, pose):
+    cfg = SC("p", 2000, 120, 90, deg[0], deg[1], 0.03, 3.0, True, 4, False)
+    test_port_equals_verbatim_reference(None, 25, make_kw=dict(pose=pose, alloc=(3, 2)), cfg=cfg)
+
+
+@pytest.mark.parametrize("pose", list(synth.POSES))
+def test_mark_visible_matches(pose):
+    scene = synth.make_scene(SC("p", 500, 64, 64, 0, 0, 0.03, 1.0, True, 4, True), seed=3, pose=pose)
     scene["means3D"][::3, 2] = -5.0
     a = pyoracle.mark_visible(scene["means3D"], scene["world_view_transform"], scene["full_proj_transform"], kind="port")
     b = pyoracle.mark_visible(scene["means3D"], scene["world_view_transform"], scene["full_proj_transform"], kind="reference")
