@@ -28,6 +28,10 @@ working and changes what happens underneath:
 together as soon as ANY of them received a gradient since the gradients were last cleared; one that received none is stepped with a
 zero gradient (its moments decay, it moves on them) -- the state the reference's loop is in anyway, where every backward reaches
 all nine.  If ALL of them are ``None`` (cleared by ``zero_grad()`` or by hand, no backward since) nothing is stepped, as in torch.
+**One step count for the bucket**: ``torch.optim.Adam`` counts steps per parameter and does not count a skipped one, so after the
+reference's ``reset_opacity`` (the opacity tensor is replaced between backward() and step(): no gradient, skipped, train.py:243-249)
+its opacity lags one step behind the other eight tensors in the bias corrections ``1 - beta^t``; here all nine share the bucket's
+count.  The reference resets at iteration 3000 at the earliest, where one step changes the corrections by 5e-5 relative.
 
 Anything else in ``param_groups`` (a group without one of the nine names) is stepped tensor by tensor with the same kernel.
 Gradients that reach a parameter through plain autograd (another loss term, the Python-SH branch of ``render()``) are absorbed:

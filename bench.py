@@ -94,6 +94,16 @@ def parse_args():
     ap.add_argument("--clustered-steps", type=int, default=10,
                     help="workload C3 only: steps of the extra leg on C3-clustered (70 %% of the Gaussians on 15 %% of the image: tile lists of "
                          "thousands of entries, some beyond the 4096 the LDS sort takes) -- what the skew of a trained scene costs (0 = skip)")
+    ap.add_argument("--cameras", choices=("rig", "axis"), default="rig",
+                    help="rig (default): the views of a step come from DIFFERENT rotated, off-axis cameras (fdgs.synth.POSES rig0..rig3 by global "
+                         "view index, one of them with the centre-shift projection) -- every real step does (a DyNeRF rig has ~20, "
+                         "scene/cameras.py:65-71); axis: every view through the one unrotated on-axis camera of rounds 1-4 (timed as the "
+                         "secondary leg value_axis_camera either way)")
+    ap.add_argument("--axis-steps", type=int, default=20,
+                    help="steps of the extra leg that re-times the step with the OTHER --cameras setting (0 = skip)")
+    ap.add_argument("--c5-steps", type=int, default=6,
+                    help="workload C3, N = 1 only: steps of the extra leg on C5 (BASELINE configs[4]: 2 M Gaussians, 2704x2028, the HBM stress "
+                         "configuration): images/s, per-stage GB/s, end-to-end algorithmic GB/s, roofline of its dominant kernel (0 = skip)")
     ap.add_argument("--no-lazy", action="store_true",
                     help="A/B: every forward waits for its num_rendered (as the reference does) instead of fdgs_forward_out.lazy")
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
@@ -321,9 +331,103 @@ def dropin_leg(args, scene, cams, gts, pipe, bg, dev, B):
                     "the reference's train.py:104-170 with one import swapped; images_s_with_fused_loss: the same with fdgs.loss.fused_l1_ssim"}
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic_r*.json")))
+def c5_leg(args, dev, make_cams, pipe, B):
+    """BASELINE configs[4] (2 M Gaussians, 2704x2028, SH degree 3: "HBM-bound stress; rocprof GB/s vs roofline") through the same
+    step as `value`: images/s on two streams, the per-stage table of a single-stream pass with every stage's algorithmic bytes and
+    GB/s, the end-to-end algorithmic GB/s (all stages' bytes / wall time per view) and the roofline entry of its dominant kernel
+    with the HBM traffic of the committed C5 counter passes (profiles/pmc_traffic_r??_C5.json)."""
+    from fdgs import _capi, synth, train_host
+    from fdgs.pipeline import StepPipeline
+    cfg = synth.CONFIGS["C5"]
+    scene = synth.make_scene(cfg, seed=0)
+    model = train_host.GaussianParams(scene, dev)
+    opt = train_host.make_optimizer(model)
+    if args.storage_order == "morton":
+        train_host.spatial_sort(model, opt)
+    snap = (model.flat.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+
+    def restore():
+        model.flat.data.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2]); opt.step_count = 0
+
+    cams = make_cams(scene, args.cameras)
+    bg = scene["bg"].to(dev)
+    W, H = scene["W"], scene["H"]
+    gts = [torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(4321 + b)).to(dev) for b in range(B)]
+    kw = dict(world_size=1, lambda_dssim=0.2, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+    # single-stream stage pass (kernel time per stage)
+    sp1 = StepPipeline(model, opt, overlap=False, **kw)
+    sp1.step(cams, gts, pipe, bg)
+    restore()
+    torch.cuda.synchronize(dev)
+    _capi.profile_reset()
+    _capi.profile_enable(True)
+    res = sp1.step(cams, gts, pipe, bg)[0]
+    torch.cuda.synchronize(dev)
+    _capi.profile_enable(False)
+    prof = _capi.profile_read()
+    del sp1
+    R = sum(r["num_rendered"] for r in res) / len(res)
+    Pv = sum(int((r["radii"] > 0).sum().item()) for r in res) / len(res)
+    P_live = sum(int((r["viewspace_grad"] != 0).any(dim=1).sum().item()) for r in res) / len(res)
+    P, M, N, T = model.P, model.M, W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    stages, total_bytes = {}, 0
+    for name, (ms, n) in prof.items():
+        if n == 0:
+            continue
+        e = {"ms": round(ms / n, 4)}
+        key = "sh_bwd_deferred" if name == "sh_bwd" else name
+        if key in ALGO_BYTES:
+            b = ALGO_BYTES[key](P, P_live if name == "sh_bwd" else Pv, M, R, N, T)
+            e["algo_bytes"] = int(b)
+            e["gbps"] = round(b / (ms / n * 1e-3) / 1e9, 1) if ms > 0 else None
+            e["frac_of_hbm_peak"] = round(b / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None
+            total_bytes += b
+        stages[name] = e
+    # the timed two-stream steps, the dominant kernel re-measured live
+    dom = max((k for k in prof if k != "readback"), key=lambda k: prof[k][0])
+    sp2 = StepPipeline(model, opt, overlap=not args.no_overlap, **kw)
+    restore()
+    for _ in range(2):
+        sp2.step(cams, gts, pipe, bg)
+    restore()
+    _capi.profile_reset()
+    _capi.profile_enable(True, stages=[dom])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.c5_steps):
+        sp2.step(cams, gts, pipe, bg)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    _capi.profile_enable(False)
+    pd = _capi.profile_read()[dom]
+    dom_ms = pd[0] / max(pd[1], 1)
+    dom_bytes = ALGO_BYTES[dom](P, Pv, M, R, N, T)
+    ms_view = dt / (args.c5_steps * B) * 1e3
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    out = {"images_s": round(B * args.c5_steps / dt, 2), "ms_per_step": round(dt / args.c5_steps * 1e3, 3), "ms_per_image": round(ms_view, 4),
+           "steps": args.c5_steps, "num_rendered": int(round(R)), "visible": int(round(Pv)), "live_gaussians": int(round(P_live)),
+           "lazy_steps_redone": sp2.lazy_redone, "cameras": args.cameras,
+           "raster_ms_single_stream": round(sum(v["ms"] for v in stages.values()), 4),
+           "algo_bytes_per_view": int(total_bytes),
+           # all stages' algorithmic bytes over the WALL time per view of the two-stream step (loss + optimizer included in the time)
+           "end_to_end_algorithmic_gbps": round(total_bytes / (ms_view * 1e-3) / 1e9, 1),
+           "end_to_end_frac_of_hbm_peak": round(total_bytes / (ms_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "stages": stages,
+           "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, "C5"),
+                        "traffic_source": "committed rocprofv3 --pmc passes of the same C5 step (profiles/pmc_traffic_r??_C5.json), not this run",
+                        "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"], "launches_timed": int(pd[1]),
+                        "algo_bytes_per_launch": int(dom_bytes)},
+           "what": "BASELINE configs[4] (C5: %d Gaussians, %dx%d, SH degree %d, M = %d) through the same two-stream step as `value`, %d views per step; "
+                   "stages: one single-stream step, HIP events per stage" % (P, W, H, cfg.sh_degree, M, B)}
+    del sp2, model, opt, snap
+    torch.cuda.empty_cache()
+    return out
+
+
+def pmc_traffic(stage, workload="C3"):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (tools/pmc_traffic.py) of ``workload``, or None."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic_r??.json" if workload == "C3" else "pmc_traffic_r??_%s.json" % workload)))
     if not files:
         return None
     try:
@@ -336,7 +440,7 @@ def pmc_traffic(stage):
 
 def pmc_valu(stage):
     """VALU issue statistics of the dominant kernel from the committed SQ-counter pass (tools/pmc_sq.sh), or None."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_sq_r*.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_sq_r??.txt")))
     if not files:
         return None
     try:
@@ -388,9 +492,19 @@ def main():
         train_host.spatial_sort(model, opt)
     pipe = train_host.PipelineFlags()
     B = max(1, args.views_per_step)
-    # frame-parallel: the N*B views of one optimizer step are N*B different timestamps; rank r takes views r*B .. r*B+B-1
-    cams = [train_host.SyntheticCamera(scene, dev, timestamp=(rank * B + b + 0.5) / (world * B) * scene["time_duration"])
-            for b in range(B)]
+    RIG = ("rig0", "rig1", "rig2", "rig3")
+
+    def make_cams(sc, which):
+        """frame-parallel: the N*B views of one optimizer step are N*B different timestamps (and, --cameras rig, cameras: pose
+        rig{g % 4} for global view index g); rank r takes views r*B .. r*B+B-1"""
+        out = []
+        for b in range(B):
+            g = rank * B + b
+            cs = sc if which == "axis" else dict(sc, **synth.camera_for(RIG[g % len(RIG)], sc["W"], sc["H"]))
+            out.append(train_host.SyntheticCamera(cs, dev, timestamp=(g + 0.5) / (world * B) * sc["time_duration"]))
+        return out
+
+    cams = make_cams(scene, args.cameras)
     cam = cams[0]
     bg = scene["bg"].to(dev)
     # one target per GLOBAL view index: N ranks x B views see the same data as one rank x N B views
@@ -708,6 +822,35 @@ def main():
                            "--storage-order " + args.storage_order + ". morton = Morton order of the positions (train_host.spatial_sort, "
                            "the order fdgs.harness.train keeps the model in); random = the generator's order"}
 
+    # the same step through the OTHER camera set (rounds 1-4 quoted `value` on the single unrotated on-axis camera)
+    other_cams = None
+    if use_pipeline and args.axis_steps > 0:
+        which = "axis" if args.cameras == "rig" else "rig"
+        ocams = make_cams(scene, which)
+        restore()
+        for _ in range(3):
+            steppipe.step(ocams, gts, pipe, bg)
+        restore()
+        torch.cuda.synchronize(dev)
+        barrier(world)
+        to0 = time.perf_counter()
+        for _ in range(args.axis_steps):
+            ores, _l = steppipe.step(ocams, gts, pipe, bg)
+        torch.cuda.synchronize(dev)
+        barrier(world)
+        dto = max_over_ranks(time.perf_counter() - to0, world, dev)
+        other_cams = {"cameras": which, "images_s": round(world * B * args.axis_steps / dto, 2), "ms_per_step": round(dto / args.axis_steps * 1e3, 4),
+                      "steps": args.axis_steps, "num_rendered": int(round(sum(r["num_rendered"] for r in ores) / len(ores))),
+                      "visible": int(round(sum(int((r["radii"] > 0).sum().item()) for r in ores) / len(ores))),
+                      "what": "the same step with --cameras " + which + " (axis = the one unrotated camera on the z axis every view of rounds 1-4 "
+                              "went through; rig = four different rotated off-axis cameras per step)"}
+        restore()
+
+    # BASELINE configs[4]: the HBM stress configuration, every round, in the driver's line
+    c5 = None
+    if use_pipeline and world == 1 and args.workload == "C3" and args.c5_steps > 0:
+        c5 = c5_leg(args, dev, make_cams, pipe, B)
+
     # a skewed scene: the same step on C3-clustered (own model; same storage order as the main run)
     clustered = None
     if use_pipeline and world == 1 and args.workload == "C3" and args.clustered_steps > 0:
@@ -718,6 +861,7 @@ def main():
             train_host.spatial_sort(cm, co)
         csnap = (cm.flat.detach().clone(), co.exp_avg.clone(), co.exp_avg_sq.clone())
         cp = StepPipeline(cm, co, world_size=1, lambda_dssim=0.2, overlap=not args.no_overlap, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+        # (on the on-axis camera whatever --cameras says: the box is placed to project onto 15 % of THAT image, and the leg's full-size parity test uses it)
         ccams = [train_host.SyntheticCamera(cs, dev, timestamp=(b + 0.5) / B * cs["time_duration"]) for b in range(B)]
         for _ in range(3):
             cres, _l = cp.step(ccams, gts, pipe, bg)
@@ -802,9 +946,9 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 # the committed counter passes are C3 passes: no figure for another workload
-                "traffic": pmc_traffic(dom) if cfg.name == "C3" else None,
+                "traffic": pmc_traffic(dom, cfg.name) if cfg.name in ("C3", "C5") else None,
                 "traffic_source": ("committed rocprofv3 --pmc passes of the same step (profiles/pmc_traffic_r*.json: tools/collect_profiles.sh, "
-                                   "tools/pmc_traffic.py), not this run" if cfg.name == "C3" else None),
+                                   "tools/pmc_traffic.py), not this run" if cfg.name in ("C3", "C5") else None),
                 "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"],
                 "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
@@ -845,7 +989,7 @@ def main():
         "config": {"workload": ("[model stored in Morton order, as fdgs.harness.train keeps it] " if args.storage_order == "morton" else "[model stored in the generator's random order] ") + "%s: %d 4D Gaussians, %dx%d, SH degree %d + time degree %d (M=%d), rot_4d=%s, "
                                "%d views/GPU/step, L1+SSIM loss (%s), Adam" % (cfg.name, P, W, H, cfg.sh_degree, cfg.sh_degree_t,
                                                                         M, cfg.rot_4d, B, "PyTorch" if args.torch_loss else "fused HIP") + (", reference host path" if args.reference_host else (", fused activations, explicit fwd/loss/bwd on %s" % ("one stream" if args.no_overlap else "two HIP streams") if use_pipeline else ", fused activations, autograd")),
-                   "num_rendered": int(round(R_timed)), "tile_cull": not args.no_tile_cull, "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,
+                   "num_rendered": int(round(R_timed)), "cameras": ("4 different rotated off-axis cameras per step (fdgs.synth.POSES rig0..rig3)" if args.cameras == "rig" else "one unrotated on-axis camera for every view"), "tile_cull": not args.no_tile_cull, "visible": int(round(Pv)), "views_per_step_per_gpu": B, "global_batch": B * world,
                    "parallelism": "frame-parallel dp%d" % world, "mode": mode},
         "forward_mpix_s": round(world * n_fwd * N / dt_fwd / 1e6, 1),
         "forward_split_colour": bool(use_pipeline and args.split_colour != "off"),
@@ -864,6 +1008,12 @@ def main():
     if per_rank:
         out["per_rank"] = per_rank
     out["backend"] = backend if backend else "none (single process)"
+    if other_cams:
+        out["value_%s_camera" % other_cams["cameras"]] = other_cams["images_s"]
+        out["other_cameras"] = other_cams
+    if c5:
+        out["c5_images_s"] = c5["images_s"]
+        out["c5"] = c5
     if clustered:
         out["clustered_images_s"] = clustered["images_s"]
         out["clustered"] = clustered
@@ -887,7 +1037,8 @@ def main():
         out["dropin_forward_ms"] = dropin["forward_ms"]
         out["dropin"] = dropin
     if world == 1 and args.cpu_samples > 0:
-        out["cpu_baseline"] = cpu_baseline(scene, args.cpu_samples)
+        cb_scene = scene if args.cameras == "axis" else dict(scene, **synth.camera_for("rig0", scene["W"], scene["H"]))
+        out["cpu_baseline"] = cpu_baseline(cb_scene, args.cpu_samples)
     print(json.dumps(out))
 
 
