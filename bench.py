@@ -1005,6 +1005,11 @@ def main():
         "roofline": roofline,
     }
     out["rccl_ranks"] = world
+    if world > 1:
+        # what the ranks exchanged per step (fdgs/pipeline.py): the views' 32-byte SH stages by all-gather + the 17 geometry floats by
+        # all-reduce (up to 32 views per step over all ranks), or the dense 161 P-float gradient bucket by all-reduce
+        out["sh_exchange"] = ("stage all-gather + geometry all-reduce" if (use_pipeline and not args.dense_sh_exchange and world * B <= 32)
+                              else "dense gradient all-reduce")
     if per_rank:
         out["per_rank"] = per_rank
     out["backend"] = backend if backend else "none (single process)"

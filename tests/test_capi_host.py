@@ -163,3 +163,15 @@ def test_fdgs_adam_rejects_what_it_does_not_implement():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError, match="GPU"):
         opt.step()
+
+
+def test_blend_bwd_inline_asm_register_allocation():
+    """csrc/blend_bwd.hip's joint DPP reductions take b[] as plain inputs that are read after a[] has been written; that no b[k]
+    shares a VGPR with an a[j] is checked in the gfx950 assembly the compiler produces (tools/check_reduce_regs.py), so that a
+    compiler bump cannot break it silently."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_reduce_regs", os.path.join(ROOT, "tools", "check_reduce_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sizes = [r[0] for r in mod.check()]
+    assert 9 in sizes and 12 in sizes

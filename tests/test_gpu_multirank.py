@@ -81,7 +81,7 @@ def _run_bench(nproc, views, extra=()):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + common
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
@@ -96,6 +96,26 @@ def test_two_ranks_make_the_same_update_as_one(dense, gpu_device):
     assert two["replicas_identical"] is True and two["config"]["global_batch"] == one["config"]["global_batch"] == 4
     (s1, a1), (s2, a2) = one["param_digest"], two["param_digest"]
     assert abs(a1 - a2) <= 1e-5 * a1 and abs(s1 - s2) <= 1e-5 * a1, (one["param_digest"], two["param_digest"])
+
+
+@pytest.mark.parametrize("views", [4, 1])
+def test_eight_ranks_make_the_same_update_as_one(views, gpu_device):
+    """The N = 8 control flow the driver's scaling run takes, before an 8-GPU box shows up: 8 ranks (all on cuda:0, gloo) x ``views``
+    views per step against 1 rank x 8 ``views`` views.  views = 4: global batch 32 = gather_max_views, the LAST batch size that
+    still exchanges the views' SH stages ([B, 8, P, 8] gather buffer); views = 1: BASELINE configs[3] as specified (8 timesteps, one
+    per rank).  rank -> view mapping (global view g = rank * B + b: the same timestamps, cameras and targets as the single rank's),
+    replicas bit-identical, the same update, per-rank exchange time reported."""
+    one = _run_bench(1, 8 * views, ["--reflists-steps", "0", "--axis-steps", "0"])
+    eight = _run_bench(8, views, ["--reflists-steps", "0", "--axis-steps", "0"])
+    assert eight["n_gpus"] == 8 and eight["rccl_ranks"] == 8 and eight["replicas_identical"] is True
+    assert eight["config"]["global_batch"] == one["config"]["global_batch"] == 8 * views
+    assert eight["sh_exchange"].startswith("stage all-gather"), eight["sh_exchange"]
+    assert eight["gpu_max_hw_queues"] == "8"
+    (s1, a1), (s2, a2) = one["param_digest"], eight["param_digest"]
+    assert abs(a1 - a2) <= 1e-5 * a1 and abs(s1 - s2) <= 1e-5 * a1, (one["param_digest"], eight["param_digest"])
+    pr = eight["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["exchange_exposed_ms"] is not None and len(pr["exchange_exposed_ms"]) == 8
+    print("8 ranks x %d views on one GPU: per-rank ms/step %s, exchange exposed ms %s" % (views, pr["ms_per_step"], pr["exchange_exposed_ms"]))
 
 
 def _run_bench_rccl(nproc, views, extra=()):

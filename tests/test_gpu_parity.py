@@ -299,11 +299,12 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, 
     # scale / rotation matrices: the chain amplifies a 1e-6 relative rounding difference in the blend backward's per-Gaussian
     # sums -- thousands of fp32 atomics per Gaussian, in whatever order the hardware issues them -- by two to three orders of
     # magnitude, in ANY implementation incl. the reference itself.  So for these four tensors the bar is
-    #     |hip - ref| <= max(1e-4 * scale, COV_CHAIN_K * max|ref - ref'|)   or   max|hip - f64| <= max|ref - f64|,
-    # ref' = the reference's own arithmetic with its atomics in another legal order (measured above, same inputs, same views),
-    # f64 = the reference's arithmetic with the per-Gaussian sums accumulated in double:
-    # the HIP kernels may differ from the reference by no more than COV_CHAIN_K times what the reference differs from itself, or
-    # must be at least as close to the double-accumulated sums as the reference is (whose accumulation error is it?).
+    #     |hip - ref| <= 1e-4 * scale,   else   max|hip - f64| <= max|ref - f64|   (primary),   else   |hip - ref| <= COV_CHAIN_K * max|ref - ref'|,
+    # f64 = the reference's arithmetic with the per-Gaussian sums accumulated in double, ref' = the reference's own arithmetic with
+    # its atomics in another legal order (measured above, same inputs, same views):
+    # the HIP kernels must be at least as close to the double-accumulated sums as the reference is (whose accumulation error is
+    # it?), or -- the fallback, one sample of a noisy quantity -- differ from the reference by no more than COV_CHAIN_K times what
+    # the reference differs from itself.
     cov_chain = ("_scaling", "_scaling_t", "_rotation", "_rotation_r")
     for n in model.NAMES:
         want = total[n].reshape(got[n].shape)
@@ -318,33 +319,36 @@ def _timed_path_vs_oracle(cfg, dev, n_views, label, max_border, tile_cull=True, 
         f64 = total_f64[n].reshape(got[n].shape)
         just[n] = "hip-ref %.2e | ref-ref' %.2e (%d beyond 1e-4) | hip-f64 %.2e | ref-f64 %.2e" % (
             err, spread, int((spread_d > 1e-4 * scale).sum()), float(np.abs(got[n] - f64).max()), float(np.abs(want - f64).max()))
-        bound = 1e-4 * scale
-        closer_to_f64 = False
-        if n in cov_chain:
-            bound = max(bound, COV_CHAIN_K * spread)
-            # (the spread is ONE sample of the reference's order noise and its maximum sits on another element every time: the second
-            # criterion is the sturdier one -- HIP at least as close to the double-accumulated sums as the reference itself, and
-            # within 1e-2 of the scale of the reference in any case)
-            closer_to_f64 = _closer_to_f64(got[n], want, f64, scale, err)
-        if not (err <= bound or closer_to_f64):
+        # the plain bar first; for the four covariance-chain tensors, beyond it: PRIMARY criterion = at least as close to the
+        # double-accumulated sums as the reference itself (does not depend on a draw); FALLBACK = within COV_CHAIN_K x the reference's
+        # own order-to-order spread (one sample of its noise, whose maximum sits on another element every time)
+        ok, how = err <= 1e-4 * scale, "1e-4"
+        if not ok and n in cov_chain:
+            ok, how = _closer_to_f64(got[n], want, f64, scale, err), "closer to f64 than the reference"
+            if not ok:
+                ok, how = err <= COV_CHAIN_K * spread, "%g x the reference's own spread" % COV_CHAIN_K
+        just[n] += " | passed by: " + how
+        if not ok:
             i = np.unravel_index(int(np.argmax(d)), d.shape)
-            raise AssertionError("%s: accumulated gradient of %s: max abs err %g > %g (max|ref| %g; the reference's own order-to-order spread: %g) "
-                                 "at %s: got %r want %r; %d elements beyond 1e-4 of scale" % (label, n, err, bound, scale, spread, i, got[n][i], want[i], beyond))
+            raise AssertionError("%s: accumulated gradient of %s: max abs err %g > %g (max|ref| %g; the reference's own order-to-order spread: %g; "
+                                 "hip-f64 %g vs ref-f64 %g) at %s: got %r want %r; %d elements beyond 1e-4 of scale" % (
+                                     label, n, err, 1e-4 * scale, scale, spread, float(np.abs(got[n] - f64).max()), float(np.abs(want - f64).max()),
+                                     i, got[n][i], want[i], beyond))
     print("%s accumulated raw-parameter gradients over %d views (max abs err / max|ref|):" % (label, n_views), line)
     print("%s covariance-chain justification (max abs over the tensor; ref' = reference with its atomics in reverse order, f64 = double-accumulated sums):" % label,
           {n: just[n] for n in cov_chain})
     return {n: just[n] for n in model.NAMES}
 
 
-# The four covariance-chain tensors (see _timed_path_vs_oracle): HIP may differ from the reference by at most this many times
-# the reference's own accumulation-order spread on the same inputs (beyond the plain 1e-4 bar) ...
+# The four covariance-chain tensors (see _timed_path_vs_oracle), beyond the plain 1e-4 bar.  FALLBACK criterion: HIP may differ from
+# the reference by at most this many times the reference's own accumulation-order spread on the same inputs ...
 COV_CHAIN_K = 2.0
 
 
 def _closer_to_f64(got, want, f64, scale, err):
-    """... or must be at least as close to the double-accumulated sums as the reference itself (and within 1e-2 of the scale of the
-    reference in any case).  The spread is ONE sample of the reference's order noise and its maximum sits on another element every
-    time; this criterion does not depend on that draw."""
+    """... PRIMARY criterion: at least as close to the double-accumulated sums as the reference itself (and within 1e-2 of the scale
+    of the reference in any case).  The spread is ONE sample of the reference's order noise and its maximum sits on another element
+    every time; this criterion does not depend on that draw."""
     return float(np.abs(got - f64).max()) <= max(1e-4 * scale, float(np.abs(want - f64).max())) and err <= 1e-2 * scale
 
 
@@ -366,8 +370,14 @@ def test_timed_path_small_with_flags_vs_oracle(mod, pv, gpu_device):
 def test_c3_full_size_vs_oracle(tile_cull, gpu_device):
     """BASELINE configs[2] -- the configuration the metric is quoted on (300 k Gaussians, 1352x1014, M = 48) -- at
     FULL size through the path bench.py times (tile_cull = True; and with the reference's lists, bit for bit), 2 views
-    accumulated, against the port oracle."""
-    _timed_path_vs_oracle(synth.CONFIGS["C3"], gpu_device, 2, "C3", 1e-3, tile_cull=tile_cull)
+    accumulated, against the port oracle.  The views come from bench.py's cameras: the four rotated off-axis poses rig0..rig3
+    (fdgs.synth.POSES; rig2 with the centre-shift projection), two per parametrisation."""
+    _timed_path_vs_oracle(synth.CONFIGS["C3"], gpu_device, 2, "C3", 1e-3, tile_cull=tile_cull, poses=["rig0", "rig2"] if tile_cull else ["rig1", "rig3"])
+
+
+def test_c3_full_size_on_axis_camera_vs_oracle(gpu_device):
+    """The same on the unrotated on-axis camera rounds 1-4 quoted the metric on (bench.py's value_axis_camera leg), one view."""
+    _timed_path_vs_oracle(synth.CONFIGS["C3"], gpu_device, 1, "C3-axis", 1e-3, tile_cull=True)
 
 
 @pytest.mark.parametrize("tile_cull", [False, True])
@@ -404,9 +414,8 @@ def test_c3_clustered_full_size_vs_oracle(tile_cull, gpu_device):
         err = float(np.abs(got - want).max())
         spread = float(np.abs(refg_rev[k] - want).max())
         line[k] = "%.2e/%.1e" % (err, scale)
-        bound = max(1e-4 * scale, COV_CHAIN_K * spread) if k in cov_chain else 1e-4 * scale
-        ok = err <= bound or (k in cov_chain and _closer_to_f64(got, want, refg_f64[k].reshape(want.shape), scale, err))
-        assert ok, "C3-clustered: %s max abs err %g > %g (max|ref| %g, the reference's own spread %g)" % (k, err, bound, scale, spread)
+        ok = err <= 1e-4 * scale or (k in cov_chain and (_closer_to_f64(got, want, refg_f64[k].reshape(want.shape), scale, err) or err <= COV_CHAIN_K * spread))
+        assert ok, "C3-clustered: %s max abs err %g > %g (max|ref| %g, the reference's own spread %g)" % (k, err, 1e-4 * scale, scale, spread)
     print("C3-clustered R", ref["R"], "longest list", longest, rep.get("instances", ""), line)
 
 
@@ -453,10 +462,9 @@ def test_c5_full_size_forward_backward_vs_oracle(gpu_device):
             spread = float(np.abs(refg_rev[k] - want).max()) if want.size else 0.0
             beyond = int((d > 1e-4 * scale).sum())
             line[k] = "%.2e/%.1e" % (err, scale) + (" (%d of %d beyond 1e-4; ref-ref' %.2e)" % (beyond, d.size, spread) if beyond else "")
-            bound = max(1e-4 * scale, COV_CHAIN_K * spread) if k in cov_chain else 1e-4 * scale
-            ok = err <= bound or (k in cov_chain and _closer_to_f64(got, want, refg_f64[k].reshape(want.shape), scale, err))
+            ok = err <= 1e-4 * scale or (k in cov_chain and (_closer_to_f64(got, want, refg_f64[k].reshape(want.shape), scale, err) or err <= COV_CHAIN_K * spread))
             assert ok, "C5 %s: %s max abs err %g > %g (max|ref| %g, reference's own spread %g), %d elements beyond 1e-4" % (
-                variant, k, err, bound, scale, spread, beyond)
+                variant, k, err, 1e-4 * scale, scale, spread, beyond)
         print("C5 %s gradients (max abs err / max|ref|):" % variant, line)
     o.close()
 
