@@ -124,3 +124,45 @@ def test_adam_step_range_equals_whole_step(gpu_device):
             ob.step_range(lo, hi)
     torch.cuda.synchronize()
     assert torch.equal(a.flat, b.flat) and torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+
+
+def test_adam_segment_kernel_equals_general_kernel(gpu_device):
+    """fdgs_adam_step takes the per-segment kernel (one segment per blockIdx.y: the learning rate is a workgroup constant) when the
+    segment table tiles [0, n), and the general kernel (per-element search) otherwise.  Same arithmetic: bit-identical parameters and
+    moments -- with segment boundaries that are not multiples of 4, a segment shorter than a float4, a periodic head (the SH DC
+    rate), a segment that starts before the chunk (negative begin: step_range) and one that ends behind it."""
+    import ctypes as C
+    from fdgs import _capi
+    n = 4 * 2503 + 3
+    g = torch.Generator(device="cpu").manual_seed(3)
+    grad = (torch.randn(n, generator=g) * 1e-2).to(gpu_device)
+    grad[::5] = 0.0
+    bounds = [-77, 3, 5, 1000, 1001, 4099, 7001, n + 50]     # segments [b_i, b_i+1): clipped to [0, n) they tile it
+    segs = []
+    for i, (b, e) in enumerate(zip(bounds[:-1], bounds[1:])):
+        period, head = (21, 3) if i in (3, 5) else (0, 0)
+        segs.append(_capi.FdgsAdamSegment(b, e, 1e-3 * (i + 1), 5e-2 * (i + 1), period, head))
+    tiling = (_capi.FdgsAdamSegment * len(segs))(*segs)
+    # the same table with the last segment cut one element short of n: does not tile -> general kernel; element n - 1 gets lr = 0
+    segs2 = list(segs)
+    segs2[-1] = _capi.FdgsAdamSegment(bounds[-2], n - 1, segs[-1].lr, segs[-1].lr_head, 0, 0)
+    general = (_capi.FdgsAdamSegment * len(segs2))(*segs2)
+
+    def run(table):
+        gen = torch.Generator(device="cpu").manual_seed(4)
+        p = torch.randn(n, generator=gen).to(gpu_device)
+        m = (0.01 * torch.randn(n, generator=gen)).to(gpu_device)
+        v = (1e-4 * torch.rand(n, generator=gen)).to(gpu_device)
+        for step in (1, 2, 3):
+            rc = _capi.lib.fdgs_adam_step(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, table, len(segs), 0.9, 0.999, 1e-15, step,
+                                          _capi.current_stream_handle(gpu_device))
+            assert rc == 0
+        torch.cuda.synchronize()
+        return p, m, v
+    a, b = run(tiling), run(general)
+    for x, y in zip(a, b):
+        assert torch.equal(x[:n - 1], y[:n - 1])
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])          # the moments of the last element update either way
+    assert float((a[0][n - 1] - b[0][n - 1]).abs()) > 0.0               # ... its parameter only where a segment covers it
+    p0 = torch.randn(n, generator=torch.Generator(device="cpu").manual_seed(4)).to(gpu_device)
+    assert float((a[0] - p0).abs().min()) > 0.0 or bool((grad == 0).any())
