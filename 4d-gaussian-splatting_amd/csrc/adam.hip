@@ -12,6 +12,7 @@
 //   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "fdgs_common.h"
 
 namespace fdgs
@@ -176,7 +177,8 @@ extern "C" int fdgs_adam_step(float* params, const float* grads, float* exp_avg,
 		at = e;
 	}
 	tiles = tiles && at == n;
-	if (tiles && aligned)
+	static const bool force_general = []() { const char* e = getenv("FDGS_ADAM_GENERAL"); return e && e[0] == '1'; }();   // A/B timing switch
+	if (tiles && aligned && !force_general)
 	{
 		const int bx = (int)std::min<long long>((longest / 4 + 255) / 256 + 1, 256 * 8);
 		hipLaunchKernelGGL(adam_seg_kernel, dim3(bx, num_segments), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,

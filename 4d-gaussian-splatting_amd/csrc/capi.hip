@@ -533,8 +533,8 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	if ((!in->dL_dout_color && !in->dL_dout_depth && !in->dL_dout_alpha && !in->dL_dout_flow) ||
 	    !in->radii || !in->out_means3D || !in->geom_buffer || !in->binning_buffer || !in->image_buffer)
 		return fail(FDGS_ERR_INVALID_ARG, "backward inputs must not be NULL");
-	if (!out->dL_dmeans2D || !out->dL_dcolors || !out->dL_dopacity || !out->dL_dmeans3D || !out->dL_dcov3D ||
-	    !out->dL_dflows || !out->grad_accum || (s.shs && !out->dL_dsh && !out->sh_stage))
+	// (dL_dcolors / dL_dcov3D / dL_dflows may be NULL: per-view outputs the caller does not want)
+	if (!out->dL_dmeans2D || !out->dL_dopacity || !out->dL_dmeans3D || !out->grad_accum || (s.shs && !out->dL_dsh && !out->sh_stage))
 		return fail(FDGS_ERR_INVALID_ARG, "backward outputs must not be NULL");
 	if (s.cov3D_precomp == nullptr)
 	{

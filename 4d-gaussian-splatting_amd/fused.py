@@ -50,19 +50,20 @@ def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, sc
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
                  prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=None, after_sh=None,
-                 sh_stage=None, begin_only=False):
+                 sh_stage=None, begin_only=False, per_view_outputs=True):
     """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple.
     ``begin_only``: only the blend backward (``_C.backward_begin``): returns the pending call for ``_C.sh_backward_batch`` /
-    ``_C.backward_finish``."""
+    ``_C.backward_finish``.  ``per_view_outputs=False``: dL_dcolors / dL_dcov3D / dL_dflows are not written (None in the tuple)."""
     e = torch.Tensor([])
     args = (rs.bg, means3D, out_means3D, radii, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
             rotation_r_raw, rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
             rs.tanfovy, g_color, g_depth, g_alpha, g_flow, sh, rs.sh_degree, rs.sh_degree_t, rs.campos,
             rs.timestamp, rs.time_duration, rs.rot_4d, rs.gaussian_dim, rs.force_sh_3d, geom, R, binb, img, rs.debug)
     if begin_only:
-        return _C.backward_begin(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum, sh_stage=sh_stage)
+        return _C.backward_begin(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum, sh_stage=sh_stage,
+                                 per_view_outputs=per_view_outputs)
     return _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum,
-                                           after_sh=after_sh, sh_stage=sh_stage)
+                                           after_sh=after_sh, sh_stage=sh_stage, per_view_outputs=per_view_outputs)
 
 
 def raw_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0):

@@ -234,7 +234,7 @@ class _NativeRasterizer:
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
                                      imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False, grad_accum=None,
-                                     after_sh=None, sh_stage=None, _phase=None):
+                                     after_sh=None, sh_stage=None, per_view_outputs=True, _phase=None):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
@@ -245,7 +245,8 @@ class _NativeRasterizer:
         ``after_sh``: a callable invoked between the blend + SH backward and the geometry backward (two native calls,
         fdgs_backward_out.stage_mask): dL_dsh is final at that point, so a data-parallel caller can start its all-reduce;
         ``sh_stage``: a [P,8] float32 scratch tensor -> deferred SH gradient (fdgs_backward_out.sh_stage): dL_dsh is not
-        touched by this call, ``_capi.sh_flush`` builds it from the stages of all views of the step."""
+        touched by this call, ``_capi.sh_flush`` builds it from the stages of all views of the step;
+        ``per_view_outputs=False``: dL_dcolors, dL_dcov3D and dL_dflows are not written (NULL at the C ABI) and come back as None."""
         dev = means3D.device
         # The reference always receives four dense tensors (autograd materialises zeros).  Here an image gradient may
         # be None = "no upstream gradient": the kernels then skip that term (colour-only backward when only
@@ -286,6 +287,8 @@ class _NativeRasterizer:
                                     _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R))
         if accumulate and not grad_out:
             raise RuntimeError("fdgs: accumulate=True needs grad_out buffers that already hold gradients")
+        if not per_view_outputs:
+            g["dL_dcolors"] = g["dL_dcov3D"] = g["dL_dflows"] = None
         ptrs = [_capi._ptr(g[k]) for k in (
             "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dflows", "dL_dts",
             "dL_dscales", "dL_dscales_t", "dL_drotations", "dL_drotations_r")]

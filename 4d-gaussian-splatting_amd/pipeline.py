@@ -197,7 +197,7 @@ class StepPipeline:
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
                                      self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh,
-                                     sh_stage=self._sh_stage[b] if defer_sh else None)
+                                     sh_stage=self._sh_stage[b] if defer_sh else None, per_view_outputs=False)
                 loss = l1_ssim_loss(loss_handle)   # the small reduction goes behind the backward, off the critical path
             # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
             keep.append((geom, binb, img, out_means3D, g_color, T))
@@ -300,7 +300,7 @@ class StepPipeline:
                 g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
                 pend.append(raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r,
                                          prefilter_var, geom, R, binb, img, g_color, None, None, None, self.sink, b > 0,
-                                         grad_accum=self._gacc_b[b], sh_stage=self._sh_stage[b], begin_only=True))
+                                         grad_accum=self._gacc_b[b], sh_stage=self._sh_stage[b], begin_only=True, per_view_outputs=False))
                 losses.append(l1_ssim_loss(loss_handle))
                 if (b + 1) % G == 0 or b == B - 1:
                     first = b - (b % G)

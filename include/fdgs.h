@@ -189,12 +189,13 @@ typedef struct fdgs_backward_out
 {
 	uint32_t struct_size;   /* sizeof(fdgs_backward_out)                           */
 	float* dL_dmeans2D;     /* [P,3]  (x,y in NDC-scaled units, z = depth carrier, Q10) */
-	float* dL_dcolors;      /* [P,3]                                               */
+	float* dL_dcolors;      /* [P,3]   or NULL: not wanted (as dL_dcov3D, dL_dflows: per-view outputs of the reference's binding that no
+	                           parameter gradient is read from -- a training step saves their 44 bytes per Gaussian and view) */
 	float* dL_dopacity;     /* [P]                                                 */
 	float* dL_dmeans3D;     /* [P,3]                                               */
-	float* dL_dcov3D;       /* [P,6]                                               */
+	float* dL_dcov3D;       /* [P,6]   or NULL                                     */
 	float* dL_dsh;          /* [P,M,3]                                             */
-	float* dL_dflows;       /* [P,2]                                               */
+	float* dL_dflows;       /* [P,2]   or NULL                                     */
 	float* dL_dts;          /* [P]                                                 */
 	float* dL_dscales;      /* [P,3]                                               */
 	float* dL_dscales_t;    /* [P]                                                 */

@@ -572,3 +572,40 @@ def test_step_pipeline_lazy_equals_waiting_and_redoes_an_overflowing_step(gpu_de
     np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=1e-5, atol=1e-6)
     perr = (runs[True][0] - runs[False][0]).abs()
     assert (perr > 2e-3).float().mean().item() <= 2e-3 and perr.max().item() <= 0.25   # (Adam on float-atomics noise: see above)
+
+
+def test_backward_without_the_per_view_outputs(gpu_device):
+    """fdgs_backward_out.dL_dcolors / dL_dcov3D / dL_dflows = NULL (``per_view_outputs=False``, what StepPipeline passes): the three
+    slots come back as None, everything else -- dL_dmeans2D and every parameter gradient -- is what the full call writes (the two
+    calls differ only in the order of the blend backward's float atomics), and the persistent accumulator is left all zero by a
+    geometry backward that now only re-zeroes the records that hold something."""
+    from fdgs import train_host
+    from fdgs.fused import raw_backward, raw_forward, raw_settings
+    cfg = synth.SceneConfig("pvo", 7000, 208, 160, 3, 2, 0.03, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=21, pose="rig1")
+    model = train_host.GaussianParams(scene, gpu_device)
+    pipe = train_host.PipelineFlags()
+    bg = torch.zeros(3, device=gpu_device)
+    cam = train_host.SyntheticCamera(scene, gpu_device)
+    up = synth.make_upstream_grads(scene["W"], scene["H"], seed=30, scale=1e-2)["grad_color"].to(gpu_device)
+    rs, tens = raw_settings(cam, model, pipe, bg)
+    (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = tens
+    (R, color, flow, depth, T, radii, geom, binb, img, _c, om) = raw_forward(rs, *tens)
+    outs = {}
+    for full in (True, False):
+        sink = {k: torch.full_like(v, float("nan")) for k, v in model.grad_sink().items()}
+        gacc = torch.zeros((model.P, 16), device=gpu_device)
+        res = raw_backward(rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img, up, None, None, None,
+                           sink, False, grad_accum=gacc, per_view_outputs=full)
+        torch.cuda.synchronize()
+        assert float(gacc.abs().max()) == 0.0
+        outs[full] = (res, sink)
+    assert all(outs[True][0][i] is not None for i in (1, 4, 6)) and all(outs[False][0][i] is None for i in (1, 4, 6))
+    assert float(outs[True][0][4].abs().max()) > 0.0
+    a, b = outs[True][0][0], outs[False][0][0]
+    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+    for k, want in outs[True][1].items():
+        got = outs[False][1][k]
+        assert torch.isfinite(got).all(), k
+        sc = max(1e-6, float(want.abs().max()))
+        assert float((got - want).abs().max()) <= 3e-4 * sc, k   # (atomics order through the covariance chain: as test_sh_backward_batch_matches_per_view)
