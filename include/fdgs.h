@@ -384,6 +384,13 @@ int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t C, int32_t 
                           const float* dm_dmu1, const float* dm_de11, const float* dm_de12,
                           const float* upstream, float lambda_dssim, float* dL_dimg, void* stream);
 int fdgs_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W);
+/* Value and gradient in ONE pass (what a training step needs; same arithmetic, bit-identical results): dL_dimg = upstream[0] *
+ * d loss / d img and the per-tile partial sums for fdgs_l1_ssim_loss, without the three derivative maps of the two-call path
+ * travelling through memory (a workgroup rebuilds the derivative maps around its tile from the images: more arithmetic, a third
+ * of the HBM traffic).  utils/loss_utils.py:34-64 + its autograd backward. */
+int fdgs_l1_ssim_value_and_grad(const float* img, const float* gt, int32_t C, int32_t H, int32_t W,
+                                const float* upstream, float lambda_dssim, float* dL_dimg,
+                                float* partial_l1, float* partial_ssim, void* stream);
 /* Reduces the per-tile partial sums of the forward call (fixed order: deterministic) to
  * loss_l1_ssim[0] = (1 - lambda) * L1 + lambda * (1 - SSIM), [1] = L1, [2] = SSIM   (device memory, 3 floats). */
 int fdgs_l1_ssim_loss(const float* partial_l1, const float* partial_ssim, int32_t num_partials, int32_t C, int32_t H, int32_t W,

@@ -166,3 +166,32 @@ def test_adam_segment_kernel_equals_general_kernel(gpu_device):
     assert float((a[0][n - 1] - b[0][n - 1]).abs()) > 0.0               # ... its parameter only where a segment covers it
     p0 = torch.randn(n, generator=torch.Generator(device="cpu").manual_seed(4)).to(gpu_device)
     assert float((a[0] - p0).abs().min()) > 0.0 or bool((grad == 0).any())
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64), (3, 77, 131), (1, 40, 33), (3, 31, 97), (3, 1014, 1352)])
+def test_one_kernel_value_and_grad_equals_the_two_kernel_path(shape, gpu_device):
+    """fdgs_l1_ssim_value_and_grad (the training step's loss: a workgroup rebuilds the derivative maps around its tile instead of
+    reading them back) against fdgs_l1_ssim_forward + fdgs_l1_ssim_backward: same arithmetic per pixel -- gradient, partial sums and
+    loss value equal to fp32 rounding; sizes with ragged tiles on both axes, one smaller than a tile, and the bench's."""
+    from fdgs import loss as fl
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(shape, generator=g).to(gpu_device)
+    gt = torch.rand(shape, generator=g).to(gpu_device)
+    up = torch.full((1,), 0.37, dtype=torch.float32, device=gpu_device)
+    res = {}
+    for fused in (False, True):
+        fl.ssim_options["fused"] = fused
+        try:
+            gr, handle = fl.l1_ssim_grad(img, gt, 0.2, up)
+            val = fl.l1_ssim_loss(handle)
+            torch.cuda.synchronize()
+            res[fused] = (gr.clone(), handle[0].clone(), float(val))
+        finally:
+            fl.ssim_options["fused"] = False
+    assert torch.isfinite(res[True][0]).all() and float(res[True][0].abs().max()) > 0.0
+    # (the two paths are two compilations of the same expressions: where the compiler contracts a multiply-add differs here and
+    # there -- observed 6e-7 of the gradient's scale)
+    scale = float(res[False][0].abs().max())
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-6 * scale
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(res[False][1].abs().max())
+    assert abs(res[True][2] - res[False][2]) <= 1e-6
