@@ -134,6 +134,11 @@ namespace fdgs
 	// (row stride SH_STRIDE floats: odd, so the lane-per-Gaussian reads that follow are bank-conflict free).
 	// The reference reads these 12*M bytes per Gaussian with a 12*M-byte stride between threads (forward.cu:85).
 	constexpr int SH_STRIDE = 49;
+#ifdef FDGS_PRE_WG_SYNC   // A/B: the workgroup barriers of rounds 1-4
+#define FDGS_TILE_SYNC() __syncthreads()
+#else
+#define FDGS_TILE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 	// generic path (any coefficient count / alignment): one float per lane and trip
 	__device__ __forceinline__ void stage_sh_block_scalar(float* __restrict__ tile, const float* __restrict__ shs, int g0, int P, int M,
 	                                                      int first_coeff, int ncoeff, unsigned long long alive_mask, int lane)
@@ -388,7 +393,9 @@ namespace fdgs
 			for (int blk = 0; blk < nblocks; blk++)
 			{
 				stage_sh_block(tile, a.shs, g0, a.P, a.M, 16 * blk, blk == 0 ? ncoef0 : 16, amask, lane, a.sh_vec_ok != 0);
-				__syncthreads();
+				// the tile is wave-private and the LDS executes one wave's operations in order: no workgroup barrier (which held the four
+				// waves of the workgroup in lockstep: all loading, then all evaluating) -- only the compiler must keep the order
+				FDGS_TILE_SYNC();
 				if (alive)
 				{
 					if (blk == 0) c = sh3d ? sh_color_3d(a.D, row, dir) : sh4d_block0(a.D, l, row);
@@ -399,7 +406,7 @@ namespace fdgs
 						c = add3(c, scl3(tk, sh_weighted(l, row, 0, 15, 0)));
 					}
 				}
-				__syncthreads();
+				FDGS_TILE_SYNC();
 			}
 			if (alive)
 			{

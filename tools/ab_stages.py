@@ -9,7 +9,8 @@ for r in range(rounds):
     for l in libs:
         env = dict(os.environ, FDGS_LIB=os.path.abspath(l))
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "10", "--cpu-samples", "0",
-                              "--host-cost-steps", "0"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+                              "--host-cost-steps", "0", "--dropin-steps", "0", "--spatial-order-steps", "0", "--reflists-steps", "0", "--clustered-steps", "0",
+                              "--axis-steps", "0", "--c5-steps", "0"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         res[l].append(json.loads(out))
 med = lambda xs: sorted(xs)[len(xs) // 2]
 keys = list(res[libs[0]][0]["stages"].keys())

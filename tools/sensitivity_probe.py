@@ -35,7 +35,7 @@ if what == "ssim":
 if what == "adam":
     opt.step_sh_staged = lambda *a, **k: True
     opt.step_range = lambda *a, **k: None
-sp = StepPipeline(model, opt, world_size=1, lambda_dssim=0.2, lazy=False)
+sp = StepPipeline(model, opt, world_size=1, lambda_dssim=0.2, lazy=(what == "none"))   # a skipped stage leaves garbage counts: the waiting forward
 snap = model.flat.detach().clone()
 for _ in range(30):
     sp.step(cams, gts, pipe, bg)
