@@ -10,11 +10,12 @@ python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; cut -c1-300 $O/bench_default.json
 python bench.py > $O/bench_noflags.json 2> $O/bench_noflags.err
-L="--dropin-steps 0 --spatial-order-steps 0 --reflists-steps 0 --clustered-steps 0 --host-cost-steps 0 --cpu-samples 0"
+L="--dropin-steps 0 --spatial-order-steps 0 --reflists-steps 0 --clustered-steps 0 --host-cost-steps 0 --cpu-samples 0 --axis-steps 0 --c5-steps 0"
 python bench.py --steps 20 --warmup 5 --no-lazy $L > $O/bench_nolazy.json 2>> $O/err.log
 python bench.py --steps 20 --warmup 5 --no-overlap $L > $O/bench_nooverlap.json 2>> $O/err.log
 python bench.py --steps 10 --warmup 3 --workload C5 $L > $O/bench_C5.json 2>> $O/err.log
 bash tools/collect_profiles.sh $TAG > $O/collect.log 2>&1
+bash tools/collect_profiles.sh $TAG C5 > $O/collect_C5.log 2>&1
 bash tools/run_timeline.sh > $O/timeline.log 2>&1
 cp gpurun_out/timeline/step_timeline.txt $O/ 2>/dev/null
 ls $O
