@@ -24,7 +24,7 @@ STAGE_OF = {
     "radix_hist_kernel": "radix_sort", "radix_scan_kernel": "radix_sort", "radix_scatter_kernel": "radix_sort",
     "tile_bin_lds_kernel<false>": "tile_count", "tile_bin_direct_kernel<false>": "tile_count", "tile_scan_kernel": "tile_scan",
     "tile_bin_lds_kernel<true>": "tile_scatter", "tile_bin_direct_kernel<true>": "tile_scatter", "tile_sort_kernel": "tile_sort",
-    "ssim_fwd_kernel": "ssim_fwd", "ssim_bwd_kernel": "ssim_bwd", "sh_bwd_kernel": "sh_bwd", "adam_kernel": "adam",
+    "ssim_fwd_kernel": "ssim_fwd", "ssim_bwd_kernel": "ssim_bwd", "sh_bwd_kernel": "sh_bwd", "adam_kernel": "adam", "adam_seg_kernel": "adam", "sh_flush_kernel": "sh_flush", "ssim_fused_kernel": "ssim_fused",
 }
 
 
