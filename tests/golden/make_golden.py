@@ -33,6 +33,15 @@ FIXTURES = {
     # (forward.cu:333, 434, backward.cu:746), on the rot_4d path and on the 3D-covariance + temporal-marginal path
     "rot4d_sh1t1_mod07_pf02": (SC("g", 500, 88, 72, 1, 1, 0.05, 4.0, True, 4, False), 15, dict(random_flow=True, bg=(0.1, 0.0, 0.3))),
     "dim4_norot_sh2_mod16_pf005": (SC("g", 500, 96, 64, 2, 0, 0.03, 1.0, False, 4, True), 16, dict()),
+    # round 5 -- general cameras (fdgs.synth.POSES: every entry of the view / projection matrices live: forward.cu:198-237,
+    # backward.cu:486-617, 878-894) and M = 48 allocated with lower degrees active (scene/gaussian_model.py:65,92,253-257):
+    # a rotated rig camera with the centre-shift projection; the slanted one (Gaussians behind z <= 0.2 and beyond the 1.3 tanfov
+    # clamp, auxiliary.h:153, forward.cu:206-211); degrees (1, 0) and (3, 1) active of the allocated (3, 2), on rotated cameras
+    "rot4d_sh3t2_rig2": (SC("g", 500, 96, 72, 3, 2, 0.05, 10.0, True, 4, False), 17, dict(random_flow=True, bg=(0.3, 0.2, 0.1), pose="rig2")),
+    "rot4d_sh3t1_slant": (SC("g", 1500, 96, 72, 3, 1, 0.04, 4.0, True, 4, False), 18, dict(pose="slant")),
+    "dim3_sh2_rig0": (SC("g", 700, 100, 60, 2, 0, 0.04, 1.0, False, 3, False), 19, dict(random_flow=True, pose="rig0")),
+    "rot4d_alloc48_deg10_rig1": (SC("g", 500, 88, 72, 1, 0, 0.05, 4.0, True, 4, False), 20, dict(pose="rig1", alloc=(3, 2), bg=(0.1, 0.0, 0.3))),
+    "rot4d_alloc48_deg31_rig3": (SC("g", 500, 88, 72, 3, 1, 0.05, 4.0, True, 4, False), 21, dict(pose="rig3", alloc=(3, 2), random_flow=True)),
 }
 # scene-dict overrides applied after make_scene (the flags travel in the fixture as sc_scale_modifier / sc_prefilter_var)
 OVERRIDES = {
