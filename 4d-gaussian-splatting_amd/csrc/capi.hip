@@ -116,16 +116,22 @@ extern "C" int fdgs_profile_read(int stage, double* total_ms, int64_t* samples)
 }
 extern "C" const char* fdgs_stage_name(int stage) { return (stage >= 0 && stage < FDGS_NUM_STAGES) ? STAGE_NAMES[stage] : ""; }
 
-// TIMING PROBE ONLY (tools/sensitivity_probe.py): FDGS_TIMING_PROBE_SKIP=<bit mask over FDGS_STAGE_*> in the environment makes the
-// library NOT launch those stages -- every result is then garbage; what is measured is how much of a stage's time the two-stream
-// step actually pays for (the upper bound of what optimising that kernel can return).  Never set by the product, the tests or bench.py.
+// TIMING PROBE ONLY, compiled in with -DFDGS_TIMING_PROBE (tools/sensitivity_probe.py builds its own copy of the library into
+// tools/ab/; the in-tree build cannot skip anything): FDGS_TIMING_PROBE_SKIP=<bit mask over FDGS_STAGE_*> in the environment makes
+// that copy NOT launch those stages -- every result is then garbage; what is measured is how much of a stage's time the two-stream
+// step actually pays for (the upper bound of what optimising that kernel can return).
+#ifdef FDGS_TIMING_PROBE
 static const unsigned g_probe_skip = []() { const char* e = getenv("FDGS_TIMING_PROBE_SKIP"); return e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();
+#define FDGS_STAGE_SKIPPED(id) (((g_probe_skip >> (id)) & 1u) != 0u)
+#else
+#define FDGS_STAGE_SKIPPED(id) false
+#endif
 
 // debug mode == the reference's CHECK_CUDA(..., debug): synchronise and check after each stage
 #define STAGE(id, expr, what)                                                                       \
 	do {                                                                                            \
 		StageTimer timer__(id, stream);                                                             \
-		if (!((g_probe_skip >> (id)) & 1u)) HIP_TRY((expr), what);                                  \
+		if (!FDGS_STAGE_SKIPPED(id)) HIP_TRY((expr), what);                                         \
 		if (debug) HIP_TRY(hipStreamSynchronize(stream), what);                                     \
 	} while (0)
 

@@ -2,7 +2,9 @@
 NOT launched (FDGS_TIMING_PROBE_SKIP, csrc/capi.hip: results are garbage, only the time is looked at) or, for the stages outside
 the rasterizer, replaced by a no-op in Python: the difference to the unmodified step is the upper bound of what optimising that
 stage can return in images/s -- as opposed to its single-stream duration, most of which may be hidden under another stream's kernel.
-Run on the GPU box:  python tools/sensitivity_probe.py            (one child process per configuration)."""
+The skipping exists only in a copy of the library built with -DFDGS_TIMING_PROBE:
+    FDGS_EXTRA_FLAGS=-DFDGS_TIMING_PROBE tools/ab_build.sh HEAD probe        (here, before gpurun)
+Run on the GPU box:  python tools/sensitivity_probe.py            (one child process per configuration; uses tools/ab/libfdgs_probe.so)."""
 import os
 import subprocess
 import sys
@@ -60,6 +62,7 @@ def run(what, mask):
     env.pop("FDGS_TIMING_PROBE_SKIP", None)
     if mask:
         env["FDGS_TIMING_PROBE_SKIP"] = str(mask)
+        env["FDGS_LIB"] = os.path.join(ROOT, "tools", "ab", "libfdgs_probe.so")   # the in-tree library cannot skip stages
     out = subprocess.run([sys.executable, "-c", CHILD, what], env=env, capture_output=True, text=True, timeout=600)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
     if not line:
