@@ -114,16 +114,22 @@ def test_all_culled_and_empty(gpu_device):
     assert hip["R"] == 0 and np.allclose(hip["out_T"], 1.0)
 
 
-def test_c2_full_size(gpu_device):
-    """BASELINE configs[1]: 100k Gaussians, 800x800, SH degree 3, forward + backward against the oracle."""
-    scene = synth.make_scene(synth.CONFIGS["C2"], seed=0)
+@pytest.mark.parametrize("pose", ["axis", "rig1"])
+def test_c2_full_size(pose, gpu_device):
+    """BASELINE configs[1]: 100k Gaussians, 800x800, SH degree 3, forward + backward against the oracle -- on the unrotated on-axis
+    camera and on a rotated, off-axis one (upstream gradients zeroed on the oracle-flagged cliff pixels on both sides there)."""
+    scene = synth.make_scene(synth.CONFIGS["C2"], seed=0, pose=pose)
     grads = synth.make_upstream_grads(scene["W"], scene["H"], seed=1, scale=GRAD_SCALE)
+    if pose != "axis":
+        ref0, _ = run_oracle(scene, None, kind="port")
+        keep = torch.from_numpy(~ref0["border"].astype(bool)).to(torch.float32)
+        grads = {k: v * keep.reshape((1,) * (v.dim() - 2) + (scene["H"], scene["W"])) for k, v in grads.items()}
     hip, hipg = run_hip(scene, gpu_device, grads)
     ref, refg = run_oracle(scene, grads, kind="port")
-    rep = check_forward(hip, ref, "C2", max_border=5e-4)
-    repg = check_backward(hipg, refg, "C2")
-    print("C2 R", ref["R"], rep)
-    print("C2", {k: "%.2e/%.1e" % v for k, v in repg.items()})
+    rep = check_forward(hip, ref, "C2 " + pose, max_border=5e-4)
+    repg = check_backward(hipg, refg, "C2 " + pose)
+    print("C2", pose, "R", ref["R"], rep)
+    print("C2", pose, {k: "%.2e/%.1e" % v for k, v in repg.items()})
 
 
 @pytest.mark.parametrize("name", ["rot4d_sh3_t2", "C1_rot4d_sh0", "ragged_33x17"])
@@ -425,7 +431,8 @@ def test_c5_full_size_forward_backward_vs_oracle(gpu_device):
     colour only.  As on C3 the upstream gradients are zeroed on the oracle-flagged cliff pixels on both sides; the bar is
     1e-4 * max(1, max|ref|) per tensor; the four covariance-chain tensors: max(that, COV_CHAIN_K x the reference's own
     accumulation-order spread on the same inputs) (see _timed_path_vs_oracle)."""
-    scene = synth.make_scene(synth.CONFIGS["C5"], seed=0)
+    # (round 5: through a rotated, off-axis camera with the centre-shift projection -- what bench.py's c5 leg renders)
+    scene = synth.make_scene(synth.CONFIGS["C5"], seed=0, pose="rig2")
     W, H = scene["W"], scene["H"]
     o = pyoracle.Oracle(scene, kind="port")
     ref = dict(o.forward())

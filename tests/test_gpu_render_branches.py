@@ -21,9 +21,9 @@ class _Pipe:
     env_map_res = 0
 
 
-def _setup(cfg, dev, seed=6, prefilter_var=-1.0):
+def _setup(cfg, dev, seed=6, prefilter_var=-1.0, pose="axis"):
     from fdgs import train_host
-    scene = synth.make_scene(cfg, seed=seed, bg=(0.1, 0.3, 0.2))
+    scene = synth.make_scene(cfg, seed=seed, bg=(0.1, 0.3, 0.2), pose=pose)
     model = train_host.ReferenceStyleModel(scene, dev)
     model.prefilter_var = prefilter_var
     cam = train_host.SyntheticCamera(scene, dev)
@@ -55,8 +55,9 @@ def _conjugated(model):
     return other
 
 
+@pytest.mark.parametrize("pose", ["axis", "rig3"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_python_covariance_matches_kernel_covariance(name, gpu_device):
+def test_python_covariance_matches_kernel_covariance(name, pose, gpu_device):
     """render() with pipe.compute_cov3D_python against render() with the in-kernel covariance.
 
     rot_4d: the model's get_current_covariance_and_mean_offset (L L^T with L = R4 S, gaussian_model.py:34-47) is the kernel's
@@ -69,7 +70,7 @@ def test_python_covariance_matches_kernel_covariance(name, gpu_device):
     from fdgs.gaussian_renderer import render
     cfg, mod, pv = CASES[name]
     from fdgs import train_host
-    scene = synth.make_scene(cfg, seed=6, bg=(0.1, 0.3, 0.2))
+    scene = synth.make_scene(cfg, seed=6, bg=(0.1, 0.3, 0.2), pose=pose)   # (rig3: a rotated, off-axis camera: scene/cameras.py:65-71)
     if cfg.gaussian_dim == 4 and not cfg.rot_4d:
         scene["scales_t"] = scene["scales_t"] * 0.03   # (a variance here, forward.cu:431-437) small enough for the 0.05 mask to remove some
     model = train_host.ReferenceStyleModel(scene, gpu_device)
@@ -139,12 +140,13 @@ def test_python_covariance_matches_kernel_covariance(name, gpu_device):
                 name, n, float(d.max()), scale)
 
 
-def test_environment_map_compositing(gpu_device):
+@pytest.mark.parametrize("pose", ["axis", "rig1"])
+def test_environment_map_compositing(pose, gpu_device):
     """pipe.env_map_res != 0: black background inside the rasterizer, then render + (1 - alpha) * env(ray), the environment
     looked up on a sphere of radius 60 around the origin (gaussian_renderer/__init__.py:41, 165-177)."""
     from fdgs.gaussian_renderer import render
     cfg = SC("e", 3000, 176, 128, 1, 0, 0.03, 1.0, True, 4, True)
-    scene, model, cam = _setup(cfg, gpu_device)
+    scene, model, cam = _setup(cfg, gpu_device, pose=pose)
     bg = torch.tensor([0.9, 0.8, 0.7], device=gpu_device)   # must be ignored: the rasterizer composites over black
     g = torch.Generator().manual_seed(3)
     model.env_map = torch.rand(3, 32, 64, generator=g).to(gpu_device).requires_grad_(True)
@@ -156,8 +158,12 @@ def test_environment_map_compositing(gpu_device):
     # PyTorch statement of the lookup, written from the formulas: ray-sphere intersection, spherical coordinates, bilinear sample
     o, d = cam.get_rays()
     assert d.shape == (scene["H"], scene["W"], 3) and torch.allclose(d.norm(dim=-1), torch.ones_like(d[..., 0]), atol=1e-5)
-    # the central ray looks down the camera's +z axis (synth.make_camera: no rotation)
-    assert torch.allclose(d[scene["H"] // 2, scene["W"] // 2], torch.tensor([0.0, 0.0, 1.0], device=gpu_device), atol=2e-2)
+    # the central ray looks down the camera's +z axis: the third column of the camera-to-world rotation (= the third row of the
+    # transposed world-to-view matrix the Camera stores, scene/cameras.py:65); (0, 0, 1) for the unrotated camera
+    zaxis = scene["world_view_transform"][:3, 2].to(gpu_device)
+    assert torch.allclose(d[scene["H"] // 2, scene["W"] // 2], zaxis / zaxis.norm(), atol=2e-2)
+    if pose == "axis":
+        assert torch.allclose(zaxis, torch.tensor([0.0, 0.0, 1.0], device=gpu_device))
     od, dd, oo = (o * d).sum(-1), (d * d).sum(-1), (o * o).sum(-1)
     t = -od + torch.sqrt(od ** 2 - dd * (oo - 60.0 ** 2)) / dd
     x = o + d * t.unsqueeze(-1)
