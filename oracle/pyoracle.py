@@ -18,6 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_SO = os.path.join(HERE, "liboracle_port.so")
 REF_SO = os.path.join(HERE, "_ref", "liboracle_ref.so")
+REF_FMA_SO = os.path.join(HERE, "_ref", "liboracle_ref_fma.so")   # the same source with FP contraction ON (build_ref.py --contract)
 
 _F = C.POINTER(C.c_float)
 _U32 = C.POINTER(C.c_uint32)
@@ -61,10 +62,11 @@ def build_port(force=False):
     return PORT_SO
 
 
-def build_ref():
-    """Compile the verbatim-reference oracle if /root/reference is present; returns path or None."""
+def build_ref(contract=False):
+    """Compile the verbatim-reference oracle if /root/reference is present; returns path or None.
+    ``contract``: also the build with FP contraction on (liboracle_ref_fma.so)."""
     script = os.path.join(HERE, "refbuild", "build_ref.py")
-    rc = subprocess.call([sys.executable, script], stdout=subprocess.DEVNULL)
+    rc = subprocess.call([sys.executable, script] + (["--contract"] if contract else []), stdout=subprocess.DEVNULL)
     return REF_SO if rc == 0 and os.path.exists(REF_SO) else None
 
 
@@ -84,6 +86,10 @@ def _load(kind):
         if not os.path.exists(REF_SO):
             raise FileNotFoundError(REF_SO + " (run oracle/refbuild/build_ref.py where /root/reference exists)")
         path = REF_SO
+    elif kind == "reference_fma":
+        if not os.path.exists(REF_FMA_SO):
+            raise FileNotFoundError(REF_FMA_SO + " (run oracle/refbuild/build_ref.py --contract where /root/reference exists)")
+        path = REF_FMA_SO
     else:
         raise ValueError(kind)
     lib = C.CDLL(path)

@@ -39,6 +39,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--opt", default="-O2")
+    ap.add_argument("--contract", action="store_true",
+                    help="ALSO build oracle/_ref/liboracle_ref_fma.so: the same source with -ffp-contract=fast -mfma, i.e. with the "
+                         "compiler free to fuse a multiply and an add into one FMA the way nvcc does by default -- not nvcc's choices "
+                         "(no CUDA toolchain exists here), but the same KIND of perturbation: tests/test_oracle_pin.py measures how far "
+                         "the reference's own outputs move under it (what 'bit-exact' can and cannot mean against a CUDA device)")
     args = ap.parse_args()
     dgr = os.path.join(args.reference, "diff-gaussian-rasterization")
     cr = os.path.join(dgr, "cuda_rasterizer")
@@ -71,6 +76,12 @@ def main():
                "-I", os.path.join(dgr, "third_party", "glm"), "-I", knn,
                "-o", out] + [os.path.join(HERE, s) for s in srcs]
         subprocess.check_call(cmd)
+        if args.contract:
+            out_fma = os.path.join(OUT_DIR, "liboracle_ref_fma.so")
+            cmd_fma = [c for c in cmd if c != "-ffp-contract=off"]
+            cmd_fma[cmd_fma.index(out)] = out_fma
+            cmd_fma[4:4] = ["-ffp-contract=fast", "-mfma", "-DORACLE_KIND_NAME=\"reference_fma\""]
+            subprocess.check_call(cmd_fma)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     print(out)

@@ -100,5 +100,8 @@ extern "C" void oracle_free(oracle_io* io)
 	io->keys_sorted = nullptr; io->point_list = nullptr;
 }
 
-extern "C" const char* oracle_kind(void) { return "reference"; }
+#ifndef ORACLE_KIND_NAME
+#define ORACLE_KIND_NAME "reference"
+#endif
+extern "C" const char* oracle_kind(void) { return ORACLE_KIND_NAME; }   // "reference_fma": the build with FP contraction on (build_ref.py --contract)
 extern "C" int oracle_threads(void) { return omp_get_max_threads(); }
