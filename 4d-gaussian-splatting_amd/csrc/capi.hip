@@ -381,7 +381,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	} join_guard{ stream, aux, joined };
 	const uint16_t* rect = (const uint16_t*)(geom + GL.rect);
 	const float* depths = (const float*)(geom + GL.depths);
-	STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
+	// (the count pass is enqueued further down, once it is known whether this forward needs one: sparse lists do not)
 	// num_rendered (and the longest tile list) come back through a pinned, device-mapped mailbox that the scan kernel
 	// writes itself: {R, longest, ticket}, one slot of a small ring per forward.  The host spins on the ticket -- the forward's
 	// one wait for the device, as rasterizer_impl.cu:302, without a copy kernel and a stream synchronisation (~10 us); if the
@@ -407,7 +407,6 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	const int slot = (int)(seq % MAIL_SLOTS);
 	const uint32_t ticket = ticket_of(seq);
 	volatile uint32_t* const mail = box.host + 4 * slot;
-	STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev + 4 * slot, ticket, tile_order, stream), "tile scan");
 
 	// Run-ahead.  The reference stops here until num_rendered has come back and sizes the binning buffers with it
 	// (rasterizer_impl.cu:302-306): the device idles for a host round trip in the middle of the forward.  Views follow each
@@ -446,9 +445,46 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		ahead_cap = std::min<long long>((((rmax + rmax / 2 + 65536) >> 18) + 1) << 18, 0x7fffffffLL);
 		ahead_longest = lmax + lmax / 2 + 64;
 	}
+	// SPARSE lists (fdgs_forward_out.sparse_lists, lazy forwards only): tile t's list gets the fixed slots [t * cap, (t + 1) * cap) of the
+	// binning buffer, cap = the longest list provided for (a multiple of 64: the cull planes' words).  Then nobody needs the lists'
+	// starts before the scatter pass -- no count pass, no scan: the scatter counts as it goes (the tile counters start from zero),
+	// the per-tile sort reads each tile's count, and one extra workgroup of its launch reports num_rendered / the longest list and
+	// writes the blend kernels' tile order.  Two launches (~16 us at C3) off the forward's critical chain for address space:
+	// T * cap instead of num_rendered entries (C3: 8.5 M instead of 2.0 M; 288 GB of HBM: DESIGN.md section 4.3).
+	uint32_t sparse_cap = 0u;
+	if (lazy && out->sparse_lists != 0 && tile_order != nullptr && ahead_longest > 0)
+	{
+		const long long cap_tile = ((long long)ahead_longest + 63) / 64 * 64;
+		if (cap_tile * (long long)T <= 0x7fffffffLL) sparse_cap = (uint32_t)cap_tile;
+	}
+	if (sparse_cap == 0u)
+	{
+		STAGE(FDGS_STAGE_TILE_COUNT, launch_tile_count(rect, P, gx, T, counters, stream), "tile count");
+		STAGE(FDGS_STAGE_TILE_SCAN, launch_tile_scan(counters, T, ctl, box.dev + 4 * slot, ticket, tile_order, stream), "tile scan");
+	}
 	char* bin = nullptr;
 	BinLayout BL = bin_layout(0, false, T);
 	bool has_scratch = false;   // BL includes the global sort scratch
+	if (sparse_cap != 0u)
+	{
+		const long long total = (long long)sparse_cap * T;
+		has_scratch = (int)sparse_cap > lds_cap;
+		BL = bin_layout((int)total, has_scratch, T);
+		bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
+		if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
+		uint32_t* pairs = (uint32_t*)(bin + BL.pairs);
+		STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)total, nullptr, stream, sparse_cap), "tile scatter (sparse)");
+		STAGE(FDGS_STAGE_TILE_SORT, launch_tile_sort(counters, T, (int)sparse_cap, pairs, point_list, ranges, has_scratch ? (void*)(bin + BL.big_scratch) : nullptr,
+		                       ctl, (uint32_t)total, nullptr, stream, sparse_cap, ctl, box.dev + 4 * slot, ticket, tile_order), "tile sort (sparse)");
+		if (!joined) { HIP_TRY(hipStreamWaitEvent(stream, aux.join, 0), "hipStreamWaitEvent"); joined = true; }
+		STAGE(FDGS_STAGE_BLEND_FWD, launch_blend_fwd(s, *out, records, point_list, ranges, tile_order, final_T, n_contrib, (unsigned long long*)(bin + BL.cull_bits),
+		                                                   BL.cull_stride, (uint32_t)(BL.cull_bits / 8), ctl, stream), "blend_fwd");
+		rec.lazy = true; rec.cap = total; rec.longest_cap = (int)sparse_cap;
+		*num_rendered = -1;
+		g_run_ahead[0]++;
+		return FDGS_OK;
+	}
 	const auto enqueue_rest = [&](long long capacity, int sort_longest, bool scatter) -> int
 	{
 		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);

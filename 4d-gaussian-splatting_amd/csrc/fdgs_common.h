@@ -133,11 +133,17 @@ namespace fdgs
 	// scatter / sort may be launched before the host knows num_rendered: they compare ctl[0] with `capacity` (the instances
 	// pairs / point_list hold) and leave everything alone -- the sort reports every tile empty -- when it does not fit
 	// tile_order (optional): one extra workgroup of this launch turns the scan's copy of the counts into the blend kernels' tile order
+	// sparse_cap != 0: SPARSE lists (fdgs_forward_out.sparse_lists): no count / scan pass ran, the counters are zero, tile t's list goes to
+	// [t * sparse_cap, (t + 1) * sparse_cap) of `pairs` / point_list; afterwards the counters hold the tiles' counts
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream);
+	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream, uint32_t sparse_cap = 0u);
 	// tile_order (optional): the order the scatter launch wrote -- the sort takes the tiles in it too (longest lists first)
+	// sparse lists: report_ctl / report_box / ticket / order_out -- the sort's main instance reports num_rendered and the longest list and
+	// writes the tile order (what the scan + scatter launches do for compact lists)
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
-	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, const uint32_t* tile_order, hipStream_t stream);
+	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, const uint32_t* tile_order, hipStream_t stream,
+	                            uint32_t sparse_cap = 0u, uint32_t* report_ctl = nullptr, uint32_t* report_box = nullptr, uint32_t ticket = 0u,
+	                            uint32_t* order_out = nullptr);
 	int tile_sort_lds_cap();                                   // lists longer than this need the global scratch
 	void tile_sort_debug_limits(int lds_cap, int rank_max);    // test hook (fdgs_debug_tile_sort_limits); <= 0 restores the default
 

@@ -143,7 +143,8 @@ namespace fdgs
 	                                                             int grid_x, int T, int rounds /* batch = rounds * BIN_T Gaussians per workgroup */,
 	                                                             uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
 	                                                             const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                             uint32_t* __restrict__ order /* [3 T + 16] or NULL */, int band)
+	                                                             uint32_t* __restrict__ order /* [3 T + 16] or NULL */, int band,
+	                                                             uint32_t sparse_cap /* 0, or SPARSE lists: tile t's list lives at [t * sparse_cap, (t + 1) * sparse_cap) */)
 	{
 		extern __shared__ uint32_t s_hist[];   // max(T, 8 * ORDER_BUCKETS) words
 		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
@@ -153,7 +154,9 @@ namespace fdgs
 			return;
 		}
 		// launched before the host knew num_rendered (capi.hip): `pairs` holds `capacity` instances -- more than that: leave everything alone
-		if (SCATTER && ctl[0] > capacity) return;
+		// (sparse lists: nobody has counted yet -- the counters start from zero and a tile that outgrows its sparse_cap slots drops
+		// what does not fit; its count still says so, and the host renders the view again)
+		if (SCATTER && sparse_cap == 0u && ctl[0] > capacity) return;
 		const int lane = threadIdx.x & 63;
 		for (int t = threadIdx.x; t < T; t += BIN_T) s_hist[t] = 0u;
 		__syncthreads();
@@ -185,7 +188,7 @@ namespace fdgs
 			if (SCATTER)
 			{
 #pragma unroll
-				for (int u = 0; u < 4; u++) if (c[u] != 0u) s_hist[t0 + u * BIN_T] = base[u];
+				for (int u = 0; u < 4; u++) if (c[u] != 0u) s_hist[t0 + u * BIN_T] = base[u] + (uint32_t)(t0 + u * BIN_T) * sparse_cap;   // (compact lists: + 0)
 			}
 		}
 		if (!SCATTER) return;
@@ -206,7 +209,7 @@ namespace fdgs
 #else
 			walk_rect_tiles(r, key, (uint32_t)g, grid_x, lane, [&](uint32_t tile, uint32_t k, uint32_t id) {
 				const uint32_t slot = atomicAdd(&s_hist[tile], 1u);
-				pairs[slot] = make_uint2(k, id);
+				if (sparse_cap == 0u || slot < (tile + 1u) * sparse_cap) pairs[slot] = make_uint2(k, id);
 			});
 #endif
 		}
@@ -217,7 +220,7 @@ namespace fdgs
 	__global__ void __launch_bounds__(256) tile_bin_direct_kernel(const ushort4* __restrict__ rect, const float* __restrict__ depths, int P,
 	                                                              int grid_x, uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
 	                                                              const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                              uint32_t* __restrict__ order, int T, int band)
+	                                                              uint32_t* __restrict__ order, int T, int band, uint32_t sparse_cap)
 	{
 		__shared__ uint32_t s_cls[8 * ORDER_BUCKETS];
 		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
@@ -225,7 +228,7 @@ namespace fdgs
 			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, band, ctl[1], order, s_cls);
 			return;
 		}
-		if (SCATTER && ctl[0] > capacity) return;
+		if (SCATTER && sparse_cap == 0u && ctl[0] > capacity) return;
 		const int g = blockIdx.x * blockDim.x + threadIdx.x;
 		ushort4 r = make_ushort4(0, 0, 0, 0);
 		uint32_t key = 0u;
@@ -235,7 +238,8 @@ namespace fdgs
 			else
 			{
 				const uint32_t slot = atomicAdd(&counters[tile], 1u);
-				pairs[slot] = make_uint2(k, id);
+				if (sparse_cap == 0u) pairs[slot] = make_uint2(k, id);
+				else if (slot < sparse_cap) pairs[tile * sparse_cap + slot] = make_uint2(k, id);
 			}
 		});
 	}
@@ -377,7 +381,7 @@ namespace fdgs
 	template <int THREADS, int ITEMS>
 	__device__ __forceinline__ bool tile_sort_one(const int tile, const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
 	                                              uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, u64* __restrict__ big_scratch,
-	                                              const int n_lo, const int lds_cap, const int rank_max, const int last)
+	                                              const int n_lo, const int lds_cap, const int rank_max, const int last, const uint32_t sparse_cap)
 	{
 		// LDS: lds_cap + TS_PAD depth keys, then lds_cap ids, in bucket order (8 lds_cap + 4 TS_PAD bytes); the same
 		// bytes hold the 64-bit keys of the bitonic fall-back and, at the end, the ids in final order
@@ -397,8 +401,10 @@ namespace fdgs
 #ifdef FDGS_TS_TIMELINE
 		unsigned long long tl_prev = __builtin_readcyclecounter();
 #endif
-		const uint32_t start = tile == 0 ? 0u : list_end[tile - 1];
-		const uint32_t end = list_end[tile];
+		// (sparse lists: the counter holds the tile's COUNT, its list starts at tile * sparse_cap; a count beyond sparse_cap = overflow,
+		// reported through the longest list: what fitted is sorted so that everything queued behind reads valid ids)
+		const uint32_t start = sparse_cap ? (uint32_t)tile * sparse_cap : (tile == 0 ? 0u : list_end[tile - 1]);
+		const uint32_t end = sparse_cap ? start + min(list_end[tile], sparse_cap) : list_end[tile];
 		const int n = (int)(end - start);
 		if (n_lo == 0 && tid == 0) ranges[tile] = n > 0 ? make_uint2(start, end) : make_uint2(0u, 0u);   // identifyTileRanges leaves empty tiles at the memset's (0,0)
 		if (n <= n_lo) return true;
@@ -636,24 +642,56 @@ namespace fdgs
 	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
 	                                                           int lds_cap, int rank_max, const uint32_t* __restrict__ ctl, uint32_t capacity,
 	                                                           int last /* no further instance takes what this one leaves */,
-	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T, int band)
+	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T, int band,
+	                                                           uint32_t sparse_cap, uint32_t* __restrict__ report_ctl /* sparse main instance: ctl (written) */,
+	                                                           uint32_t* __restrict__ report_box, uint32_t ticket, uint32_t* __restrict__ order_out)
 	{
-		int tile = (int)blockIdx.x;
+		if (report_ctl != nullptr && blockIdx.x == 0)
+		{
+			// (workgroup 0, so that it is dispatched first and its ~7 us of serial work run next to the tiles' sorts, not behind them)
+			// SPARSE lists, the extra workgroup of the main instance: what the scan kernel does for compact lists -- num_rendered and the
+			// longest list from the tiles' counts (final since the scatter launch) into ctl and the caller's mailbox, and the blend
+			// kernels' tile order
+			__shared__ uint32_t s_rep[8 * ORDER_BUCKETS];
+			__shared__ uint32_t s_sum[THREADS / WAVE], s_max[THREADS / WAVE];
+			uint32_t sum = 0u, mx = 0u;
+			for (int t = threadIdx.x; t < T; t += THREADS) { const uint32_t c = list_end[t]; sum += c; mx = max(mx, c); }
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+			if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
+			__syncthreads();
+			uint32_t gtot = 0u, gmax = 0u;
+#pragma unroll
+			for (int w = 0; w < THREADS / WAVE; w++) { gtot += s_sum[w]; gmax = max(gmax, s_max[w]); }
+			if (threadIdx.x == 0)
+			{
+				report_ctl[0] = gtot; report_ctl[1] = gmax;
+				if (report_box)
+				{
+					report_box[0] = gtot; report_box[1] = gmax;
+					__hip_atomic_store(&report_box[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+			}
+			if (order_out != nullptr) tile_order_block(list_end, order_out + tile_order_tmp_off(T), T, band, gmax, order_out, s_rep);
+			return;
+		}
+		const int wg = (int)blockIdx.x - (report_ctl != nullptr ? 1 : 0);
+		int tile = wg;
 		if (order != nullptr)
 		{
-			const int slot = ((int)blockIdx.x % NUM_XCDS_BIN) * band + (int)blockIdx.x / NUM_XCDS_BIN;
-			if ((int)blockIdx.x / NUM_XCDS_BIN >= band || slot >= T) return;
+			const int slot = (wg % NUM_XCDS_BIN) * band + wg / NUM_XCDS_BIN;
+			if (wg / NUM_XCDS_BIN >= band || slot >= T) return;
 			tile = (int)order[slot];
 		}
 		else if (tile >= T) return;
 		// launched before the host knew num_rendered: if the buffers are too small the scatter pass did not run either (the counters
 		// are not list ends) -- every tile is reported empty, so that whatever is queued behind reads nothing, and the host starts over
-		if (ctl[0] > capacity)
+		if (sparse_cap == 0u && ctl[0] > capacity)
 		{
 			if (n_lo == 0 && threadIdx.x == 0) ranges[tile] = make_uint2(0u, 0u);
 			return;
 		}
-		tile_sort_one<THREADS, ITEMS>(tile, list_end, pairs, point_list, ranges, big_scratch, n_lo, lds_cap, rank_max, last);
+		tile_sort_one<THREADS, ITEMS>(tile, list_end, pairs, point_list, ranges, big_scratch, n_lo, lds_cap, rank_max, last, sparse_cap);
 	}
 
 	// ------------------------------------------------------------------------------------------------
@@ -664,7 +702,7 @@ namespace fdgs
 
 	template <bool SCATTER>
 	static hipError_t launch_tile_bin(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                                  const uint32_t* ctl, uint32_t capacity, uint32_t* order, hipStream_t stream)
+	                                  const uint32_t* ctl, uint32_t capacity, uint32_t* order, hipStream_t stream, uint32_t sparse_cap = 0u)
 	{
 		if (P <= 0) return hipSuccess;
 		const ushort4* r4 = reinterpret_cast<const ushort4*>(rect);
@@ -688,11 +726,11 @@ namespace fdgs
 			}
 			const int rounds = bin_rounds(T);
 			hipLaunchKernelGGL(tile_bin_lds_kernel<SCATTER>, dim3(div_up(P, rounds * BIN_T) + extra), dim3(BIN_T),
-			                   (size_t)max(T, 8 * ORDER_BUCKETS) * 4, stream, r4, depths, P, grid_x, T, rounds, counters, p2, ctl, capacity, order, band);
+			                   (size_t)max(T, 8 * ORDER_BUCKETS) * 4, stream, r4, depths, P, grid_x, T, rounds, counters, p2, ctl, capacity, order, band, sparse_cap);
 		}
 		else
 			hipLaunchKernelGGL(tile_bin_direct_kernel<SCATTER>, dim3(div_up(P, 256) + extra), dim3(256), 0, stream, r4, depths, P, grid_x, counters, p2,
-			                   ctl, capacity, order, T, band);
+			                   ctl, capacity, order, T, band, sparse_cap);
 		return hipGetLastError();
 	}
 
@@ -710,9 +748,10 @@ namespace fdgs
 	}
 
 	hipError_t launch_tile_scatter(const uint16_t* rect, const float* depths, int P, int grid_x, int T, uint32_t* counters, uint32_t* pairs,
-	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream)
+	                               const uint32_t* ctl, uint32_t capacity, uint32_t* tile_order, hipStream_t stream, uint32_t sparse_cap)
 	{
-		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, ctl, capacity, tile_order, stream);
+		// sparse lists: the counters are still zero (no count / scan pass ran); the tile order is left to the sort launch (tile_sort_kernel)
+		return launch_tile_bin<true>(rect, depths, P, grid_x, T, counters, pairs, ctl, capacity, sparse_cap ? nullptr : tile_order, stream, sparse_cap);
 	}
 
 	// test hook: cap the list length the LDS instances take, and the crowded-bucket threshold
@@ -727,7 +766,8 @@ namespace fdgs
 	template <int THREADS, int ITEMS = TS_ITEMS>
 	static hipError_t launch_sort_instance(const uint32_t* counters, int T, const uint2* pairs, uint32_t* point_list, uint2* ranges, u64* big,
 	                                 int n_lo, int cap, int rank_max, const uint32_t* ctl, uint32_t capacity, bool last, const uint32_t* order,
-	                                 hipStream_t stream)
+	                                 hipStream_t stream, uint32_t sparse_cap = 0u, uint32_t* report_ctl = nullptr, uint32_t* report_box = nullptr,
+	                                 uint32_t ticket = 0u, uint32_t* order_out = nullptr)
 	{
 		const int band = div_up(T, NUM_XCDS_BIN);
 		const size_t lds = (size_t)cap * 8 + TS_PAD * 4;
@@ -746,13 +786,18 @@ namespace fdgs
 				if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
 			}
 		}
-		hipLaunchKernelGGL((tile_sort_kernel<THREADS, ITEMS>), dim3(order ? band * NUM_XCDS_BIN : T), dim3(THREADS), lds, stream, counters, pairs,
-		                   point_list, ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0, order, T, band);
+		hipLaunchKernelGGL((tile_sort_kernel<THREADS, ITEMS>), dim3((order ? band * NUM_XCDS_BIN : T) + (report_ctl ? 1 : 0)), dim3(THREADS), lds, stream,
+		                   counters, pairs, point_list, ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0, order, T, band,
+		                   sparse_cap, report_ctl, report_box, ticket, order_out);
 		return hipSuccess;
 	}
 
+	// sparse_cap != 0: SPARSE lists (see tile_bin_lds_kernel): `counters` hold the tiles' counts, tile t's list sits at t * sparse_cap;
+	// the main instance carries one extra workgroup (its first) that reports num_rendered / the longest list into `report_ctl` and the mailbox
+	// `report_box` (with `ticket`) and writes the blend kernels' tile order into `order_out`; max_count = the longest list PROVIDED FOR
 	hipError_t launch_tile_sort(const uint32_t* counters, int T, int max_count, const uint32_t* pairs, uint32_t* point_list, uint32_t* ranges,
-	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, const uint32_t* tile_order, hipStream_t stream)
+	                            void* big_scratch, const uint32_t* ctl, uint32_t capacity, const uint32_t* tile_order, hipStream_t stream,
+	                            uint32_t sparse_cap, uint32_t* report_ctl, uint32_t* report_box, uint32_t ticket, uint32_t* order_out)
 	{
 		const int lds_cap = g_lds_cap.load(), rank_max = g_rank_max.load();
 		const uint2* p2 = reinterpret_cast<const uint2*>(pairs);
@@ -775,25 +820,29 @@ namespace fdgs
 		const int c4 = min(1024 * TS_ITEMS, lds_cap), c5 = min(1024 * TS_ITEMS_LONG, lds_cap);
 		const auto lds_keys = [&](int c) { return min(c, max(64, div_up(longest_lds, 64) * 64)); };
 		const bool overflow = max_count > lds_cap;   // somebody has to take the global path
-		if (div_up(T, NUM_XCDS_BIN) >= (1 << 24)) tile_order = nullptr;   // no order was written (launch_tile_bin)
+		if (div_up(T, NUM_XCDS_BIN) >= (1 << 24)) { tile_order = nullptr; order_out = nullptr; }   // no order is written (launch_tile_bin)
+		if (sparse_cap) tile_order = nullptr;   // the order is only being written by this launch: tiles by index
+		const uint32_t sc = sparse_cap;
 		hipError_t e = hipSuccess;
 		if (max_count <= c1 || c2 == c1)
-			e = launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, tile_order, stream);
+			e = launch_sort_instance<128>(counters, T, p2, point_list, r2, overflow ? big : nullptr, 0, lds_keys(c1), rank_max, ctl, capacity, true, tile_order, stream,
+			                              sc, report_ctl, report_box, ticket, order_out);
 		else
 		{
 			const bool second = max_count > c2 && c3 > c2;
 			const bool third = second && longest_lds > c3 && c4 > c3;
-			e = launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, tile_order, stream);
+			e = launch_sort_instance<256>(counters, T, p2, point_list, r2, (overflow && !second) ? big : nullptr, 0, lds_keys(c2), rank_max, ctl, capacity, !second, tile_order, stream,
+			                              sc, report_ctl, report_box, ticket, order_out);
 			if (second && e == hipSuccess)
 				e = launch_sort_instance<512>(counters, T, p2, point_list, r2, (overflow && !third) ? big : nullptr, c2, lds_keys(c3), rank_max, ctl, capacity, !third, tile_order,
-				                              stream);
+				                              stream, sc);
 			if (third && e == hipSuccess)
 			{
 				if (longest_lds <= c4 || c5 == c4)
-					e = launch_sort_instance<1024>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c3, lds_keys(c4), rank_max, ctl, capacity, true, tile_order, stream);
+					e = launch_sort_instance<1024>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c3, lds_keys(c4), rank_max, ctl, capacity, true, tile_order, stream, sc);
 				else
 					e = launch_sort_instance<1024, TS_ITEMS_LONG>(counters, T, p2, point_list, r2, overflow ? big : nullptr, c3, lds_keys(c5), rank_max, ctl, capacity, true,
-					                                              tile_order, stream);
+					                                              tile_order, stream, sc);
 			}
 		}
 		if (e != hipSuccess) return e;

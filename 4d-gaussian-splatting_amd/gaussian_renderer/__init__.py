@@ -37,7 +37,8 @@ class _RasterizeModel(torch.autograd.Function):
     def forward(ctx, means2D, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, rs, opt, tile_cull, lazy):
         from ..fused import raw_forward
         (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
-            rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, tile_cull=tile_cull, lazy=lazy)
+            rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, tile_cull=tile_cull, lazy=lazy,
+            sparse_lists=lazy)   # (a lazy forward never hands its lists out: they may as well sit at fixed offsets -- no count / scan launch)
         ctx.rs, ctx.R, ctx.prefilter_var, ctx.opt = rs, R, prefilter_var, opt
         ctx.save_for_backward(xyz, out_means3D, scaling, rotation, radii, feats, opacity, ts, scaling_t, rotation_r, geom, binb, img)
         ctx.mark_non_differentiable(radii)

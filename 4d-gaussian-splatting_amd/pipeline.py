@@ -27,7 +27,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stag
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
                  fuse_sh_adam: bool = True, gather_max_views: int = 32, split_colour: bool = False, batch_views: bool = False,
-                 sh_group: int = 1, tile_cull: bool = True, lazy: bool = True):
+                 sh_group: int = 1, tile_cull: bool = True, lazy: bool = True, sparse_lists: bool = True):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -54,6 +54,9 @@ class StepPipeline:
         import os
         self.lazy = bool(lazy) and os.environ.get("FDGS_PIPELINE_LAZY", "1") != "0"   # FDGS_PIPELINE_LAZY=0: debugging switch
         self.lazy_redone = 0
+        # fdgs_forward_out.sparse_lists (with lazy): every tile's list at a fixed offset of the binning buffer -- the count and scan launches
+        # leave the forward's critical chain (FDGS_PIPELINE_SPARSE=0: debugging / A-B switch)
+        self.sparse_lists = bool(sparse_lists) and os.environ.get("FDGS_PIPELINE_SPARSE", "1") != "0"
         # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
         # is bracketed by two timing events appended to it (train_host.timed_wait): the exchange time nothing overlapped
         self.exchange_pairs = None
@@ -149,7 +152,8 @@ class StepPipeline:
                     cams[b], m, pipe, bg, scaling_modifier)
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
                     rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
-                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull, lazy=lazy and handles[b] is None)
+                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull, lazy=lazy and handles[b] is None,
+                    sparse_lists=self.sparse_lists and lazy and handles[b] is None)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):

@@ -104,6 +104,9 @@ def parse_args():
     ap.add_argument("--c5-steps", type=int, default=6,
                     help="workload C3, N = 1 only: steps of the extra leg on C5 (BASELINE configs[4]: 2 M Gaussians, 2704x2028, the HBM stress "
                          "configuration): images/s, per-stage GB/s, end-to-end algorithmic GB/s, roofline of its dominant kernel (0 = skip)")
+    ap.add_argument("--no-sparse-lists", action="store_true",
+                    help="A/B: lazy forwards with the tile lists packed back to back (count + scan launches in the forward) instead of "
+                         "fdgs_forward_out.sparse_lists (every tile's list at a fixed offset of the binning buffer: the same lists, no count / scan)")
     ap.add_argument("--no-lazy", action="store_true",
                     help="A/B: every forward waits for its num_rendered (as the reference does) instead of fdgs_forward_out.lazy")
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
@@ -353,7 +356,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
     bg = scene["bg"].to(dev)
     W, H = scene["W"], scene["H"]
     gts = [torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(4321 + b)).to(dev) for b in range(B)]
-    kw = dict(world_size=1, lambda_dssim=0.2, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+    kw = dict(world_size=1, lambda_dssim=0.2, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy, sparse_lists=not args.no_sparse_lists)
     # single-stream stage pass (kernel time per stage)
     sp1 = StepPipeline(model, opt, overlap=False, **kw)
     sp1.step(cams, gts, pipe, bg)
@@ -516,7 +519,7 @@ def main():
         from fdgs.pipeline import StepPipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
                                 gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all", tile_cull=not args.no_tile_cull,
-                                batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy)
+                                batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy, sparse_lists=not args.no_sparse_lists)
 
     def step():
         if use_pipeline:
@@ -583,7 +586,7 @@ def main():
     if use_pipeline:
         stage_pipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=False,
                                   gather_max_views=0 if args.dense_sh_exchange else 32, batch_views=args.batch_views, sh_group=args.sh_group,
-                                  tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+                                  tile_cull=not args.no_tile_cull, lazy=not args.no_lazy, sparse_lists=not args.no_sparse_lists)
         stage_step = lambda: stage_pipe.step(cams, gts, pipe, bg)[0]  # noqa: E731
     else:
         stage_step = step
@@ -702,7 +705,8 @@ def main():
             from fdgs.fused import raw_forward, raw_settings
             rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(c, model, pipe, bg)
             return raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv,
-                               split_colour=args.split_colour != "off", tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+                               split_colour=args.split_colour != "off", tile_cull=not args.no_tile_cull, lazy=not args.no_lazy,
+                               sparse_lists=not (args.no_lazy or args.no_sparse_lists))
         return render(c, model, pipe, bg) if args.reference_host else render_raw(c, model, pipe, bg)
 
     fwd_lazy_failed = 0
@@ -768,7 +772,7 @@ def main():
     reflists = None
     if use_pipeline and args.reflists_steps > 0 and not args.no_tile_cull:
         rp = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
-                          gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy)
+                          gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy, sparse_lists=False)
         restore()
         for _ in range(3):
             rp.step(cams, gts, pipe, bg)
@@ -782,7 +786,7 @@ def main():
         dtr = max_over_ranks(time.perf_counter() - tr0, world, dev)
         reflists = {"images_s": round(world * B * args.reflists_steps / dtr, 2), "ms_per_step": round(dtr / args.reflists_steps * 1e3, 4),
                     "steps": args.reflists_steps, "num_rendered": int(round(sum(r["num_rendered"] for r in rres) / len(rres))),
-                    "what": "the same step with tile_cull = 0: the tile lists are the reference's, bit for bit (tests/test_gpu_parity.py)"}
+                    "what": "the same step with tile_cull = 0 and sparse_lists = 0: point_list / ranges / n_contrib are the reference's, bit for bit (tests/test_gpu_parity.py)"}
         del rp
 
     # the same step with the model stored in Morton order (a memory-layout choice of the trainer, no effect on the arithmetic)
@@ -860,7 +864,8 @@ def main():
         if args.storage_order == "morton":
             train_host.spatial_sort(cm, co)
         csnap = (cm.flat.detach().clone(), co.exp_avg.clone(), co.exp_avg_sq.clone())
-        cp = StepPipeline(cm, co, world_size=1, lambda_dssim=0.2, overlap=not args.no_overlap, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+        cp = StepPipeline(cm, co, world_size=1, lambda_dssim=0.2, overlap=not args.no_overlap, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy,
+                          sparse_lists=not args.no_sparse_lists)
         # (on the on-axis camera whatever --cameras says: the box is placed to project onto 15 % of THAT image, and the leg's full-size parity test uses it)
         ccams = [train_host.SyntheticCamera(cs, dev, timestamp=(b + 0.5) / B * cs["time_duration"]) for b in range(B)]
         for _ in range(3):
@@ -877,7 +882,8 @@ def main():
             tf0 = time.perf_counter()
             for i in range(4 * args.clustered_steps):
                 rs_, (xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_) = raw_settings(ccams[i % B], cm, pipe, bg)
-                raw_forward(rs_, xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy)
+                raw_forward(rs_, xyz_, f_, o_, t_, s_c, st_, r_, rr_, pv_, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy,
+                            sparse_lists=not (args.no_lazy or args.no_sparse_lists))
             torch.cuda.synchronize(dev)
             dtcf = time.perf_counter() - tf0
             _capi.forward_lazy_status(dev, wait=True)
@@ -982,6 +988,9 @@ def main():
         "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4),
         "ms_per_image": round(dt / (steps_timed * B) * 1e3, 4),
         "lazy_forward": bool(use_pipeline and not args.no_lazy and world == 1), "lazy_steps_redone": lazy_redone,
+        # fdgs_forward_out.sparse_lists: lazy forwards keep every tile's list at a fixed offset of the binning buffer (the same lists; no count /
+        # scan launch: their rows are then missing from `stages`)
+        "sparse_lists": bool(use_pipeline and not args.no_lazy and not args.no_sparse_lists and world == 1),
         "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,

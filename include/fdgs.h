@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 400 /* 0.4.0.  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+#define FDGS_VERSION 500 /* 0.5.0 (round 5: fdgs_forward_out.sparse_lists).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
                             (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
                             FDGS_VERSION: a binding built against another revision of this header is turned away instead of
                             having the library read past the end of a shorter struct. */
@@ -162,6 +162,14 @@ typedef struct fdgs_forward_out
 	                         with lazy = 0 BEFORE anything irreversible depends on it (fdgs.pipeline.StepPipeline: before the optimizer
 	                         step of the views' batch).  Where it cannot run ahead (first call for a configuration, debug mode,
 	                         fdgs_set_run_ahead(0)) the call behaves as with 0 and returns num_rendered >= 0. */
+	int32_t sparse_lists; /* with lazy = 1 only (ignored otherwise).  1: the tile lists are NOT packed back to back: tile t's list occupies the
+	                         fixed slots [t * cap, t * cap + n_t) of the binning buffer, cap = the longest list the run-ahead guess provides for
+	                         (rounded up to 64).  Nothing has to know the lists' starts before the scatter pass then: the count and scan
+	                         launches disappear from the forward (4 launches in front of the blend instead of 6), the scatter counts as it goes.
+	                         The lists themselves -- which instances, in which order -- are what they are without the flag; `ranges` holds
+	                         (t * cap, t * cap + n_t) instead of the reference's prefix sums (identifyTileRanges), num_rendered (reported
+	                         lazily) is the same sum.  A list that outgrows cap is cut and the forward reported as failed, like any lazy
+	                         forward that does not fit.  Costs address space: T * cap entries of 12 bytes instead of num_rendered. */
 } fdgs_forward_out;
 
 /* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output
