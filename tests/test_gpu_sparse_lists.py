@@ -48,6 +48,10 @@ def _fwd(sc, **kw):
     ("dim3_sh2", SC("sp", 8009, 256, 256, 2, 0, 0.03, 1.0, False, 3, False), "rig0"),
     ("ragged", SC("sp", 1501, 49, 33, 1, 0, 0.05, 1.0, True, 4, True), "axis"),
     ("long_lists", SC("sp", 40013, 96, 64, 0, 0, 0.03, 1.0, True, 4, True), "axis"),        # lists of thousands of entries: the long-list sort instances
+    # at full size, where the compact forward is held to the oracle (tests/test_gpu_parity.py): the configuration the metric is quoted on
+    # through one of the bench's cameras, and its clustered variant (lists of up to 5485 entries: 45 M slots of address space)
+    ("C3", synth.CONFIGS["C3"], "rig0"),
+    ("C3-clustered", synth.CONFIGS["C3-clustered"], "axis"),
 ])
 def test_sparse_lists_are_the_compact_lists_elsewhere(name, cfg, pose, tile_cull, gpu_device):
     from fdgs import _capi
