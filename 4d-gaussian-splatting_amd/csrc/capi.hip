@@ -442,7 +442,13 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	{
 		long long rmax = 0; int lmax = 0;
 		for (int k = 0; k < 4; k++) { rmax = std::max(rmax, guess.r_hist[k]); lmax = std::max(lmax, guess.l_hist[k]); }
-		ahead_cap = std::min<long long>((((rmax + rmax / 2 + 65536) >> 18) + 1) << 18, 0x7fffffffLL);
+		// (geometric steps -- 1/16 octave, at least 256 Ki -- because a scene that grows a little every step must not present the
+		// caller's allocator with a new, slightly larger size every few steps: a device allocation of hundreds of MB in the middle
+		// of a running pipeline stalls it for milliseconds; measured on the C5 leg of bench.py, profiles/HISTORY.md round 5)
+		const long long want = rmax + rmax / 2 + 65536;
+		long long q = 1ll << 18;
+		while (q * 32 <= want) q <<= 1;
+		ahead_cap = std::min<long long>((want / q + 1) * q, 0x7fffffffLL);
 		ahead_longest = lmax + lmax / 2 + 64;
 	}
 	// SPARSE lists (fdgs_forward_out.sparse_lists, lazy forwards only): tile t's list gets the fixed slots [t * cap, (t + 1) * cap) of the
@@ -454,7 +460,10 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 	uint32_t sparse_cap = 0u;
 	if (lazy && out->sparse_lists != 0 && tile_order != nullptr && ahead_longest > 0)
 	{
-		const long long cap_tile = ((long long)ahead_longest + 63) / 64 * 64;
+		// a multiple of 64, in steps of 1/8 octave for the same reason as ahead_cap above (one step of 64 is T * 64 entries: 16 MB at C5)
+		long long q = 64;
+		while (q * 16 <= ahead_longest) q <<= 1;
+		const long long cap_tile = ((long long)ahead_longest + q - 1) / q * q;
 		if (cap_tile * (long long)T <= 0x7fffffffLL) sparse_cap = (uint32_t)cap_tile;
 	}
 	if (sparse_cap == 0u)

@@ -390,17 +390,39 @@ def c5_leg(args, dev, make_cams, pipe, B):
     dom = max((k for k in prof if k != "readback"), key=lambda k: prof[k][0])
     sp2 = StepPipeline(model, opt, overlap=not args.no_overlap, **kw)
     restore()
-    for _ in range(2):
+    # warm-up until the caller's allocator is quiet: the host runs up to a mailbox ring of forwards ahead of the device, and every
+    # forward in flight holds a binning buffer (656 MB each here) -- the depth, hence the last device allocations (tens of ms each
+    # on a busy GPU), is only reached after three or four steps
+    for k in range(8):
+        n0 = torch.cuda.memory_stats(dev)["num_device_alloc"]
         sp2.step(cams, gts, pipe, bg)
+        if k >= 2 and torch.cuda.memory_stats(dev)["num_device_alloc"] == n0:
+            break
     restore()
     _capi.profile_reset()
     _capi.profile_enable(True, stages=[dom])
     torch.cuda.synchronize(dev)
+    dbg = int(os.environ.get("FDGS_BENCH_DEBUG", "0"))     # 1: allocator / run-ahead statistics of the timed region; 2: + a synchronise per step
+    if dbg:
+        ms0, ra0 = torch.cuda.memory_stats(dev), _capi.run_ahead_stats()
+        seg0 = {(g["address"], g["total_size"]) for g in torch.cuda.memory_snapshot()}
     t0 = time.perf_counter()
     for _ in range(args.c5_steps):
+        ts = time.perf_counter()
         sp2.step(cams, gts, pipe, bg)
+        if dbg > 1:
+            th = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            print("c5 step host %.2f ms total %.2f ms" % ((th - ts) * 1e3, (time.perf_counter() - ts) * 1e3), file=sys.stderr)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    if dbg:
+        ms1, ra1 = torch.cuda.memory_stats(dev), _capi.run_ahead_stats()
+        print("c5 dbg: device allocs %d frees %d reserved %.1f GB run-ahead %s" % (
+            ms1["num_device_alloc"] - ms0["num_device_alloc"], ms1["num_device_free"] - ms0["num_device_free"],
+            ms1["reserved_bytes.all.current"] / 1e9, tuple(b - a for a, b in zip(ra0, ra1))), file=sys.stderr)
+        print("c5 dbg: new segments (MB, stream)", sorted((g["total_size"] >> 20, g["stream"]) for g in torch.cuda.memory_snapshot()
+                                                          if (g["address"], g["total_size"]) not in seg0), file=sys.stderr)
     _capi.profile_enable(False)
     pd = _capi.profile_read()[dom]
     dom_ms = pd[0] / max(pd[1], 1)
