@@ -24,7 +24,7 @@ FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
 _fp = C.c_void_p  # all device pointers travel as void*
 
 
-FDGS_VERSION = 500  # include/fdgs.h; checked against fdgs_version() at import
+FDGS_VERSION = 501  # include/fdgs.h; checked against fdgs_version() at import
 
 
 class _Sized(C.Structure):
@@ -53,7 +53,7 @@ class FdgsScene(_Sized):
 class FdgsForwardOut(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
                 ("out_means3D", _fp), ("covs_com", _fp), ("preprocessed", C.c_int32), ("split_colour", C.c_int32), ("tile_cull", C.c_int32),
-                ("lazy", C.c_int32), ("sparse_lists", C.c_int32)]
+                ("lazy", C.c_int32), ("sparse_lists", C.c_int32), ("colour_stream", C.c_void_p)]
 
 
 class FdgsBackwardIn(_Sized):
@@ -301,6 +301,33 @@ class ClockSample:
     def ghz(self):
         self.stream.synchronize()
         w0, s0, w1, s1, khz = [int(x) for x in self.out.cpu().tolist()]
+        if w1 <= w0 or khz <= 0:
+            return None
+        return (s1 - s0) / (w1 - w0) * khz * 1e-6
+
+
+class ClockPair:
+    """The same measurement without a stream of its own (a step that uses four streams leaves no hardware queue for a sampler that
+    sits in one for the whole interval): two short samples on the CALLER's stream, mark() where the interval starts and mark() where it
+    ends; s_memtime is one chip-wide counter, so the shader cycles between the first sample's start and the second one's end over the
+    constant-rate ticks between them is the clock sustained in between (bench.py checks it against ClockSample: FDGS_BENCH_CLOCK=both)."""
+
+    def __init__(self, device):
+        self.dev = device
+        self.out = torch.zeros((2, 5), dtype=torch.int64, device=device)
+        self.n = 0
+
+    def mark(self):
+        with torch.cuda.device(self.dev):
+            rc = lib.fdgs_debug_clock_sample(self.out[self.n].data_ptr(), 0.002, current_stream_handle(self.dev))
+        _check(rc, "fdgs_debug_clock_sample")
+        self.n += 1
+
+    def ghz(self):
+        if self.n != 2:
+            return None
+        torch.cuda.synchronize(self.dev)
+        (w0, s0, _w, _s, khz), (_w2, _s2, w1, s1, _k) = [[int(x) for x in row] for row in self.out.cpu().tolist()]
         if w1 <= w0 or khz <= 0:
             return None
         return (s1 - s0) / (w1 - w0) * khz * 1e-6

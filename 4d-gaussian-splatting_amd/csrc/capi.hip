@@ -360,14 +360,17 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 			HIP_TRY(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming), "hipEventCreate");
 			HIP_TRY(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming), "hipEventCreate");
 		}
+		// (fdgs_forward_out.colour_stream: the caller's choice of that second stream -- whatever it has enqueued there, e.g. the update
+		// of the SH coefficients, comes before the colours, while geometry and binning on `stream` do not wait for it)
+		hipStream_t const cstream = out->colour_stream ? (hipStream_t)out->colour_stream : aux.stream;
 		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, 1, stream), "preprocess_fwd (geometry)");
 		HIP_TRY(hipEventRecord(aux.fork, stream), "hipEventRecord");
-		HIP_TRY(hipStreamWaitEvent(aux.stream, aux.fork, 0), "hipStreamWaitEvent");
+		HIP_TRY(hipStreamWaitEvent(cstream, aux.fork, 0), "hipStreamWaitEvent");
 		{
-			StageTimer timer__(FDGS_STAGE_COLOUR_FWD, aux.stream);
-			HIP_TRY(launch_preprocess_fwd(s, *out, geom, counters, 2, aux.stream), "preprocess_fwd (colour)");
+			StageTimer timer__(FDGS_STAGE_COLOUR_FWD, cstream);
+			HIP_TRY(launch_preprocess_fwd(s, *out, geom, counters, 2, cstream), "preprocess_fwd (colour)");
 		}
-		HIP_TRY(hipEventRecord(aux.join, aux.stream), "hipEventRecord");
+		HIP_TRY(hipEventRecord(aux.join, cstream), "hipEventRecord");
 	}
 	else
 		STAGE(FDGS_STAGE_PREPROCESS_FWD, launch_preprocess_fwd(s, *out, geom, counters, 0, stream), "preprocess_fwd");

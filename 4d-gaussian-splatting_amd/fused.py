@@ -31,13 +31,13 @@ def _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_r
 
 
 def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
-                split_colour=False, preprocessed=None, tile_cull=False, lazy=False, sparse_lists=False):
+                split_colour=False, preprocessed=None, tile_cull=False, lazy=False, sparse_lists=False, colour_stream=None):
     """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple.
     ``preprocessed``: the view's handle from ``raw_preprocess_batch``; ``tile_cull``: fdgs_forward_out.tile_cull; ``lazy``:
-    fdgs_forward_out.lazy (num_rendered comes back as -1, the host does not wait); ``sparse_lists``: fdgs_forward_out.sparse_lists."""
+    fdgs_forward_out.lazy (num_rendered comes back as -1, the host does not wait); ``sparse_lists``: fdgs_forward_out.sparse_lists; ``colour_stream``: fdgs_forward_out.colour_stream (a torch.cuda.Stream)."""
     args = _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
     return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour, preprocessed=preprocessed, tile_cull=tile_cull, lazy=lazy,
-                                  sparse_lists=sparse_lists)
+                                  sparse_lists=sparse_lists, colour_stream=colour_stream)
 
 
 def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,

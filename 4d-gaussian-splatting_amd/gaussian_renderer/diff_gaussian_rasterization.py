@@ -118,7 +118,7 @@ class _NativeRasterizer:
                             scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
                             gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False, preprocessed=None,
-                            tile_cull=False, lazy=False, sparse_lists=False):
+                            tile_cull=False, lazy=False, sparse_lists=False, colour_stream=None):
         """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49).
         Keyword-only extensions: ``raw_params``: the scale / opacity / rotation tensors are the model's raw
         parameters and the kernels apply the activations (fdgs_scene.raw_params); ``split_colour``: the SH colour evaluation
@@ -127,7 +127,8 @@ class _NativeRasterizer:
         pixels and gradients, shorter tile lists); ``lazy``: fdgs_forward_out.lazy -- the call does not wait for num_rendered
         (returned as -1; the backward takes it) and ``_capi.forward_lazy_status`` later says whether the run-ahead buffers fitted;
         ``sparse_lists`` (with ``lazy``): fdgs_forward_out.sparse_lists -- every tile's list at a fixed offset of the binning buffer, no
-        count / scan launches."""
+        count / scan launches; ``colour_stream`` (with ``split_colour``): the torch.cuda.Stream the colour launch goes onto instead of
+        the library's own (fdgs_forward_out.colour_stream)."""
         if not means3D.is_cuda:
             raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
         dev = means3D.device
@@ -158,7 +159,7 @@ class _NativeRasterizer:
                                    _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com),
                                    int(preprocessed is not None), int(bool(split_colour)),
                                    int(preprocessed["tile_cull"] if preprocessed is not None else bool(tile_cull)), int(bool(lazy)),
-                                   int(bool(sparse_lists)))
+                                   int(bool(sparse_lists)), colour_stream.cuda_stream if colour_stream is not None else None)
         R = C.c_int32(0)
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), scratch.callback, None,
@@ -186,7 +187,7 @@ class _NativeRasterizer:
                  "tile_cull": bool(tile_cull)}
             h["scratch"].reuse = True
             h["out"] = _capi.FdgsForwardOut(None, None, None, None, _capi._ptr(h["radii"]), _capi._ptr(h["out_means3D"]),
-                                            _capi._ptr(h["covs_com"]), 0, 0, int(bool(tile_cull)), 0, 0)
+                                            _capi._ptr(h["covs_com"]), 0, 0, int(bool(tile_cull)), 0, 0, None)
             handles.append(h)
         B = len(handles)
         scenes = (C.POINTER(_capi.FdgsScene) * B)(*[C.pointer(h["scene"]) for h in handles])

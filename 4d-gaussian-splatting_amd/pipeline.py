@@ -27,7 +27,7 @@ from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stag
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
                  fuse_sh_adam: bool = True, gather_max_views: int = 32, split_colour: bool = False, batch_views: bool = False,
-                 sh_group: int = 1, tile_cull: bool = True, lazy: bool = True, sparse_lists: bool = True):
+                 sh_group: int = 1, tile_cull: bool = True, lazy: bool = True, sparse_lists: bool = True, overlap_steps: bool = False):
         """``fuse_sh_adam``: on one rank the SH coefficients are updated straight from the views'
         staged SH gradients (FlatAdam.step_sh_staged) and ``_features.grad`` is NOT materialised for the step; False keeps
         the flush into the gradient bucket followed by the plain Adam step (always the case on several ranks, where the
@@ -57,6 +57,21 @@ class StepPipeline:
         # fdgs_forward_out.sparse_lists (with lazy): every tile's list at a fixed offset of the binning buffer -- the count and scan launches
         # leave the forward's critical chain (FDGS_PIPELINE_SPARSE=0: debugging / A-B switch)
         self.sparse_lists = bool(sparse_lists) and os.environ.get("FDGS_PIPELINE_SPARSE", "1") != "0"
+        # ``overlap_steps`` (one rank, two streams, fused SH update; opt-in because it is a promise of the caller's): the head of step
+        # k + 1 under the tail of step k.  89 % of the parameters are SH coefficients and their update (HBM-bound, 1.08 GB at C3: ~216 us)
+        # is the last thing of a step -- but geometry, binning and sort of the next step's first view read no SH coefficient.  The SH
+        # update goes onto a third stream A; the first view of the next step is a split_colour forward whose colour launch goes onto A
+        # as well (fdgs_forward_out.colour_stream: in order behind the update, no event), while its geometry + binning + sort run on
+        # stream F as soon as the GEOMETRY parameters' Adam step (23 us, stream B) is through.  Same kernels on the same numbers: the
+        # parameters after n steps are bit-identical with and without (tests/test_gpu_api.py).
+        # The promise: between two step() calls the caller enqueues nothing on ITS stream that writes the model / optimizer state or
+        # that the next forwards depend on, and is done with the previous step's result tensors -- or it calls barrier() first (stream F
+        # does not wait for the caller's stream at the start of such a step).  A model whose flat tensor was replaced or modified
+        # through torch (densification, reset_opacity: the version counter moves) is noticed and treated like barrier().
+        self.overlap_steps = (bool(overlap_steps) and bool(overlap) and int(world_size) == 1 and bool(fuse_sh_adam)
+                              and os.environ.get("FDGS_PIPELINE_OVERLAP_STEPS", "1") != "0")
+        self._carry = None    # what the model looked like when the last step left its SH update running on stream A
+        self.steps_carried = 0
         # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
         # is bracketed by two timing events appended to it (train_host.timed_wait): the exchange time nothing overlapped
         self.exchange_pairs = None
@@ -83,6 +98,7 @@ class StepPipeline:
         # load imbalance / ~100 ns same-address atomics than the overlap returns.  See DESIGN.md.)
         self.sF = torch.cuda.Stream(dev)
         self.sB = torch.cuda.Stream(dev) if overlap else self.sF
+        self.sA = torch.cuda.Stream(dev) if self.overlap_steps else None
         self.sink = model.grad_sink()
         self._up = {}
         self._gacc = None   # persistent, always-zero blend-backward accumulator (no memset per view)
@@ -96,6 +112,15 @@ class StepPipeline:
             with torch.cuda.stream(self.sB):
                 self._up[B] = torch.full((1,), 1.0 / (B * self.world), dtype=torch.float32, device=self.dev)
         return self._up[B]
+
+    def barrier(self):
+        """overlap_steps: the caller has touched the model, the optimizer state or anything else the next step reads on its stream --
+        the next step() waits for that stream before its first launch (as every step does without overlap_steps)."""
+        self._carry = None
+
+    def _model_token(self):
+        m = self.model
+        return (id(m.flat), m.flat._version, m.P, m.flat.data_ptr())
 
     def step(self, cams: Sequence, gts: Sequence[torch.Tensor], pipe, bg: torch.Tensor, scaling_modifier: float = 1.0):
         """Runs forward + loss + backward of every view, the gradient all-reduce and the optimizer step.
@@ -113,11 +138,19 @@ class StepPipeline:
         has been enqueued then)."""
         B = len(cams)
         main = torch.cuda.current_stream(self.dev)
-        self.sF.wait_stream(main)
+        m = self.model
+        # overlap_steps: stream F has waited for stream B (the geometry parameters' Adam step included) at the end of the previous step;
+        # the caller's stream has nothing new for the forwards (the promise) but waits for the SH update on stream A -- so F must not
+        # wait for it.  B does: its first launch of the step is the first view's loss, behind that view's colours anyway
+        carried = self.overlap_steps and self._carry is not None and self._carry == self._model_token()
+        self._carry = None
+        if carried:
+            self.steps_carried += 1
+        else:
+            self.sF.wait_stream(main)
         if self.sB is not self.sF:
             self.sB.wait_stream(main)
         up = self._upstream(B)
-        m = self.model
         if self._gacc is None or self._gacc.shape[0] != m.P:
             with torch.cuda.stream(self.sB):
                 self._gacc = torch.zeros((m.P, 16), dtype=torch.float32, device=self.dev)
@@ -152,8 +185,9 @@ class StepPipeline:
                     cams[b], m, pipe, bg, scaling_modifier)
                 (R, color, flow, depth, T, radii, geom, binb, img, _covs, out_means3D) = raw_forward(
                     rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
-                    split_colour=self.split_colour and handles[b] is None, tile_cull=self.tile_cull, lazy=lazy and handles[b] is None,
-                    sparse_lists=self.sparse_lists and lazy and handles[b] is None)
+                    split_colour=(self.split_colour or (b == 0 and self.sA is not None and fuse)) and handles[b] is None,
+                    colour_stream=self.sA if (b == 0 and self.sA is not None and fuse and handles[b] is None) else None,
+                    tile_cull=self.tile_cull, lazy=lazy and handles[b] is None, sparse_lists=self.sparse_lists and lazy and handles[b] is None)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
@@ -167,6 +201,8 @@ class StepPipeline:
                     if failed:
                         main.wait_stream(self.sB)
                         main.wait_stream(self.sF)
+                        if self.sA is not None:
+                            main.wait_stream(self.sA)
                         self.sF.wait_stream(self.sB)
                         return None
                     lazy_ix = [i for i, r_ in enumerate(results) if r_["num_rendered"] < 0] + ([b] if R < 0 else [])
@@ -181,11 +217,13 @@ class StepPipeline:
                 if b == B - 1 and fuse and self.sB is not self.sF:
                     # the SH stages are complete once this view's SH backward has run: the fused SH flush + Adam (HBM-bound)
                     # goes onto the idle F stream and runs next to the geometry backward (latency-bound) of stream B
+                    # (overlap_steps: onto stream A, which the next step's first view puts its colour launch on)
                     def after_sh():
                         done = torch.cuda.Event()
                         done.record(self.sB)
-                        with torch.cuda.stream(self.sF):
-                            self.sF.wait_event(done)
+                        s_up = self.sA if self.sA is not None else self.sF
+                        with torch.cuda.stream(s_up):
+                            s_up.wait_event(done)
                             self.opt.step_count += 1
                             sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
                 elif gather:
@@ -212,6 +250,12 @@ class StepPipeline:
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)
         self.sF.wait_stream(self.sB)
+        if self.sA is not None:
+            main.wait_stream(self.sA)
+            if fuse and sh_stepped and sh_stepped[0]:
+                self._carry = self._model_token()    # the next step may start under this step's SH update (see __init__)
+            else:
+                self.sF.wait_stream(self.sA)
         # The returned tensors live in the F / B streams' allocator pools.  `main` has waited for both streams, and the
         # next step() makes both streams wait for `main` first, so they are safe to read on `main` until then
         # (no record_stream: it would defer every free by an event query and grow the pools).

@@ -30,6 +30,7 @@ import json
 import os
 import sys
 import time
+import weakref
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -107,6 +108,9 @@ def parse_args():
     ap.add_argument("--no-sparse-lists", action="store_true",
                     help="A/B: lazy forwards with the tile lists packed back to back (count + scan launches in the forward) instead of "
                          "fdgs_forward_out.sparse_lists (every tile's list at a fixed offset of the binning buffer: the same lists, no count / scan)")
+    ap.add_argument("--no-overlap-steps", action="store_true",
+                    help="A/B: StepPipeline(overlap_steps=False) -- every step starts behind the previous step's SH update (default: geometry, "
+                         "binning and sort of a step's first view run next to it; one rank, two streams)")
     ap.add_argument("--no-lazy", action="store_true",
                     help="A/B: every forward waits for its num_rendered (as the reference does) instead of fdgs_forward_out.lazy")
     ap.add_argument("--cpu-samples", type=int, default=2, help="oracle forward+backward passes timed for cpu_baseline (0 = skip)")
@@ -334,13 +338,30 @@ def dropin_leg(args, scene, cams, gts, pipe, bg, dev, B):
                     "the reference's train.py:104-170 with one import swapped; images_s_with_fused_loss: the same with fdgs.loss.fused_l1_ssim"}
 
 
+_PIPES = weakref.WeakSet()
+
+
+def new_pipeline(*a, **kw):
+    """StepPipeline, registered so that models_touched() reaches it"""
+    from fdgs.pipeline import StepPipeline
+    p = StepPipeline(*a, **kw)
+    _PIPES.add(p)
+    return p
+
+
+def models_touched():
+    """The bench has written parameters / optimizer state through torch on its own stream (the restores between legs and repetitions):
+    a StepPipeline(overlap_steps=True) starts its next step only behind that (StepPipeline.barrier)."""
+    for p in list(_PIPES):
+        p.barrier()
+
+
 def c5_leg(args, dev, make_cams, pipe, B):
     """BASELINE configs[4] (2 M Gaussians, 2704x2028, SH degree 3: "HBM-bound stress; rocprof GB/s vs roofline") through the same
     step as `value`: images/s on two streams, the per-stage table of a single-stream pass with every stage's algorithmic bytes and
     GB/s, the end-to-end algorithmic GB/s (all stages' bytes / wall time per view) and the roofline entry of its dominant kernel
     with the HBM traffic of the committed C5 counter passes (profiles/pmc_traffic_r??_C5.json)."""
     from fdgs import _capi, synth, train_host
-    from fdgs.pipeline import StepPipeline
     cfg = synth.CONFIGS["C5"]
     scene = synth.make_scene(cfg, seed=0)
     model = train_host.GaussianParams(scene, dev)
@@ -351,6 +372,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
 
     def restore():
         model.flat.data.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2]); opt.step_count = 0
+        models_touched()
 
     cams = make_cams(scene, args.cameras)
     bg = scene["bg"].to(dev)
@@ -358,7 +380,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
     gts = [torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(4321 + b)).to(dev) for b in range(B)]
     kw = dict(world_size=1, lambda_dssim=0.2, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy, sparse_lists=not args.no_sparse_lists)
     # single-stream stage pass (kernel time per stage)
-    sp1 = StepPipeline(model, opt, overlap=False, **kw)
+    sp1 = new_pipeline(model, opt, overlap=False, **kw)
     sp1.step(cams, gts, pipe, bg)
     restore()
     torch.cuda.synchronize(dev)
@@ -388,7 +410,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
         stages[name] = e
     # the timed two-stream steps, the dominant kernel re-measured live
     dom = max((k for k in prof if k != "readback"), key=lambda k: prof[k][0])
-    sp2 = StepPipeline(model, opt, overlap=not args.no_overlap, **kw)
+    sp2 = new_pipeline(model, opt, overlap=not args.no_overlap, overlap_steps=not args.no_overlap_steps, **kw)
     restore()
     # warm-up until the caller's allocator is quiet: the host runs up to a mailbox ring of forwards ahead of the device, and every
     # forward in flight holds a binning buffer (656 MB each here) -- the depth, hence the last device allocations (tens of ms each
@@ -431,7 +453,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     out = {"images_s": round(B * args.c5_steps / dt, 2), "ms_per_step": round(dt / args.c5_steps * 1e3, 3), "ms_per_image": round(ms_view, 4),
            "steps": args.c5_steps, "num_rendered": int(round(R)), "visible": int(round(Pv)), "live_gaussians": int(round(P_live)),
-           "lazy_steps_redone": sp2.lazy_redone, "cameras": args.cameras,
+           "lazy_steps_redone": sp2.lazy_redone, "steps_started_under_the_previous_sh_update": sp2.steps_carried, "cameras": args.cameras,
            "raster_ms_single_stream": round(sum(v["ms"] for v in stages.values()), 4),
            "algo_bytes_per_view": int(total_bytes),
            # all stages' algorithmic bytes over the WALL time per view of the two-stream step (loss + optimizer included in the time)
@@ -538,10 +560,11 @@ def main():
     sink = None if args.reference_host else model.grad_sink()
     use_pipeline = not (args.reference_host or args.autograd or args.torch_loss or args.no_loss)
     if use_pipeline:
-        from fdgs.pipeline import StepPipeline
+        StepPipeline = new_pipeline
         steppipe = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
                                 gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all", tile_cull=not args.no_tile_cull,
-                                batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy, sparse_lists=not args.no_sparse_lists)
+                                batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy, sparse_lists=not args.no_sparse_lists,
+                                overlap_steps=not args.no_overlap_steps)
 
     def step():
         if use_pipeline:
@@ -578,6 +601,7 @@ def main():
         opt.exp_avg.copy_(snap[1])
         opt.exp_avg_sq.copy_(snap[2])
         opt.step_count = snap[3]
+        models_touched()
 
     # warm-up: --warmup steps, and on until --min-warmup-ms of wall time have passed (the driver's --warmup 5 is 15 ms of C3 steps;
     # the shader clock takes ~100 ms of load to settle)
@@ -651,10 +675,16 @@ def main():
     # (its length estimated from two more untimed steps)
     est_ms = est_step_ms * steps_timed
     clock = None
+    # (the step uses up to four streams -- the caller's, F, B, A -- and the runtime has four hardware queues by default: the sampler that sits
+    # in a queue of its own for the whole region is the A/B aid now, FDGS_BENCH_CLOCK=span|both; the default takes two short samples on the
+    # caller's stream, in front of the first and behind the last timed step)
+    clock_mode = os.environ.get("FDGS_BENCH_CLOCK", "pair")
+    clock_pair = None
     try:
-        clock = _capi.ClockSample(dev)
+        clock = _capi.ClockSample(dev) if clock_mode in ("span", "both") else None
+        clock_pair = _capi.ClockPair(dev) if clock_mode in ("pair", "both") else None
     except Exception:
-        clock = None
+        clock = clock_pair = None
     torch.cuda.synchronize(dev)
     # no collector pauses inside the timed region (the host runs ~1.8 ms ahead of the GPU per step; a generation-2 collection of the
     # step's many small Python objects takes longer than that)
@@ -667,22 +697,66 @@ def main():
     t0 = time.perf_counter()
     if clock is not None:
         clock.start(min(max(0.8 * est_ms, 1.0), 1500.0))
+    if clock_pair is not None:
+        clock_pair.mark()
+    _DBG, _host_ms = int(os.environ.get("FDGS_BENCH_DEBUG", "0")), []
     for i in range(steps_timed):
         if i % args.steps == 0:
             restore()   # inside the timed region: ~0.25 ms of copies per --steps steps (not part of any step's own event pair)
         starts[i].record()
+        if _DBG:
+            _th = time.perf_counter()
         pkg = step()
+        if _DBG:
+            _host_ms.append((time.perf_counter() - _th) * 1e3)
         ends[i].record()
+    if clock_pair is not None:
+        clock_pair.mark()
     torch.cuda.synchronize(dev)
     barrier(world)
     dt = time.perf_counter() - t0
+    if _DBG:
+        print("step dbg: event pairs (ms)", [round(starts[i].elapsed_time(ends[i]), 2) for i in range(min(steps_timed, 45))], file=sys.stderr)
+        print("step dbg: gaps between pairs (ms)", [round(ends[i].elapsed_time(starts[i + 1]), 2) for i in range(min(steps_timed - 1, 45))], file=sys.stderr)
+        print("step dbg: host (ms)", [round(h, 2) for h in _host_ms[:45]], file=sys.stderr)
     gc.enable()
     _capi.profile_enable(False)
-    shader_ghz = None
+    shader_ghz = pair_ghz = None
     try:
         shader_ghz = clock.ghz() if clock is not None else None
+        if clock_pair is not None:
+            pair_ghz = clock_pair.ghz()
+            if clock_mode == "both":
+                print("clock: spanning sampler %s GHz, two samples on the caller's stream %s GHz" % (shader_ghz, pair_ghz), file=sys.stderr)
     except Exception:
         shader_ghz = None
+    if clock is None and clock_mode == "pair" and use_pipeline:
+        # the spanning sampler (the clock every round has quoted: it counts through the moments the shader array idles, the two samples
+        # read 1.5 % less) on the same steps right behind the timed region, through a pipeline without overlap_steps: three streams + the
+        # sampler's = the four hardware queues
+        try:
+            gc.disable()
+            cpipe = new_pipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
+                                 gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all",
+                                 tile_cull=not args.no_tile_cull, batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy,
+                                 sparse_lists=not args.no_sparse_lists, overlap_steps=False)
+            restore()
+            for _ in range(3):
+                cpipe.step(cams, gts, pipe, bg)
+            torch.cuda.synchronize(dev)
+            n_clock = max(args.steps, min(steps_timed, int(300.0 / max(est_step_ms, 1e-3))))
+            clock = _capi.ClockSample(dev)
+            clock.start(min(max(0.8 * est_step_ms * n_clock, 1.0), 1500.0))
+            for _ in range(n_clock):
+                cpipe.step(cams, gts, pipe, bg)
+            torch.cuda.synchronize(dev)
+            shader_ghz = clock.ghz()
+            del cpipe
+        except Exception:
+            shader_ghz = pair_ghz
+        finally:
+            gc.enable()
+            restore()
     prof_dom = _capi.profile_read()[dom]
     # N > 1: every rank's own wall time per step and the exchange time nothing overlapped (the sum of stream B's waits for a
     # collective per step, train_host.timed_wait), so that a scaling run explains itself
@@ -794,7 +868,8 @@ def main():
     reflists = None
     if use_pipeline and args.reflists_steps > 0 and not args.no_tile_cull:
         rp = StepPipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
-                          gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy, sparse_lists=False)
+                          gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy, sparse_lists=False,
+                          overlap_steps=not args.no_overlap_steps)
         restore()
         for _ in range(3):
             rp.step(cams, gts, pipe, bg)
@@ -819,9 +894,11 @@ def main():
             opt.exp_avg.copy_(snap_random[1])
             opt.exp_avg_sq.copy_(snap_random[2])
             opt.step_count = snap_random[3]
+            models_touched()
         else:
             restore()
             train_host.spatial_sort(model, opt)
+            models_touched()
         for _ in range(3):
             step()
         torch.cuda.synchronize(dev)
@@ -887,12 +964,13 @@ def main():
             train_host.spatial_sort(cm, co)
         csnap = (cm.flat.detach().clone(), co.exp_avg.clone(), co.exp_avg_sq.clone())
         cp = StepPipeline(cm, co, world_size=1, lambda_dssim=0.2, overlap=not args.no_overlap, tile_cull=not args.no_tile_cull, lazy=not args.no_lazy,
-                          sparse_lists=not args.no_sparse_lists)
+                          sparse_lists=not args.no_sparse_lists, overlap_steps=not args.no_overlap_steps)
         # (on the on-axis camera whatever --cameras says: the box is placed to project onto 15 % of THAT image, and the leg's full-size parity test uses it)
         ccams = [train_host.SyntheticCamera(cs, dev, timestamp=(b + 0.5) / B * cs["time_duration"]) for b in range(B)]
         for _ in range(3):
             cres, _l = cp.step(ccams, gts, pipe, bg)
         cm.flat.data.copy_(csnap[0]); co.exp_avg.copy_(csnap[1]); co.exp_avg_sq.copy_(csnap[2]); co.step_count = 0
+        models_touched()
         torch.cuda.synchronize(dev)
         tc0 = time.perf_counter()
         for _ in range(args.clustered_steps):
@@ -981,20 +1059,32 @@ def main():
                 "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
                         "peak is reported as the contract asks; valu_issue_frac = VALU issue cycles per SIMD (SQ counters, "
-                        "profiles/) / kernel cycles at the shader clock measured during the timed steps is the bound this kernel actually runs against"}
+                        "profiles/) / kernel cycles at the shader clock measured under the step's load is the bound this kernel actually runs against"}
     valu = pmc_valu(dom) if cfg.name == "C3" else None   # the committed SQ-counter pass is a C3 pass
     roofline["shader_clock_ghz_measured"] = None if shader_ghz is None else round(shader_ghz, 3)
+    roofline["shader_clock_ghz_two_samples"] = None if pair_ghz is None else round(pair_ghz, 3)
+    roofline["shader_clock_note"] = ("shader_clock_ghz_measured: one wave on a stream of its own spanning ~80 % of a loop of the same steps "
+                                     "(inside the timed region with FDGS_BENCH_CLOCK=span; by default right behind it through a pipeline without "
+                                     "overlap_steps, because the timed steps use all four default hardware queues); shader_clock_ghz_two_samples: "
+                                     "two short samples on the caller's stream around the timed region itself (reads ~1.5 % less: the counter "
+                                     "rests while the shader array idles)")
     if valu:
         # instruction counts are a property of the kernel + workload (committed SQ pass, same C3 scene); the time and the clock are live
         ghz = shader_ghz if shader_ghz else 2.4
         pass_ns = valu.get("kernel_ns_in_counter_pass")
-        valu["kernel_cycles"] = int((pass_ns * 1e-9 if pass_ns else dom_ms * 1e-3) * ghz * 1e9)
-        valu["kernel_cycles_from"] = ("the kernel's duration in the counter pass x the clock measured live" if pass_ns
-                                      else "the kernel's live duration x the clock measured live")
-        valu["clock"] = ("measured during the timed steps (s_memtime / s_memrealtime sampler, fdgs_debug_clock_sample)" if shader_ghz
+        # cycles the kernel takes: its single-stream duration in THIS run (the stage pass above: since round 5 the counter pass --
+        # tools/step_loop.py -- renders the same four views) x the clock measured in this run.  The duration inside the counter pass
+        # belongs to a process of two optimizer steps whose shader clock has not settled (it is ~7 % longer than the live one for the
+        # same instruction count); the fraction with it is kept next to the other one
+        single_ms = stages[dom]["ms"] if dom in stages else dom_ms
+        valu["kernel_cycles"] = int(single_ms * 1e-3 * ghz * 1e9)
+        valu["kernel_cycles_from"] = "the kernel's single-stream duration in this run (stage pass, same views as the counter pass) x the clock measured in this run"
+        valu["clock"] = ("measured under the step's load (s_memtime / s_memrealtime sampler, fdgs_debug_clock_sample; shader_clock_note)" if shader_ghz
                          else "2.4 GHz maximum clock assumed: valu_issue_frac is a LOWER bound")
         roofline["valu"] = valu
         roofline["valu_issue_frac"] = round(valu["valu_issue_cycles_per_simd"] / max(valu["kernel_cycles"], 1), 3)
+        if pass_ns:
+            roofline["valu_issue_frac_with_counter_pass_duration"] = round(valu["valu_issue_cycles_per_simd"] / max(pass_ns * 1e-9 * ghz * 1e9, 1.0), 3)
     mode = ("weak scaling, %d views per GPU and step (the reference's DyNeRF batch per GPU)" % B if B > 1 else
             "BASELINE configs[3] as specified: one view per GPU and step, N timesteps frame-parallel")
     out = {
@@ -1013,6 +1103,8 @@ def main():
         # fdgs_forward_out.sparse_lists: lazy forwards keep every tile's list at a fixed offset of the binning buffer (the same lists; no count /
         # scan launch: their rows are then missing from `stages`)
         "sparse_lists": bool(use_pipeline and not args.no_lazy and not args.no_sparse_lists and world == 1),
+        "overlap_steps": bool(use_pipeline and steppipe.overlap_steps),
+        "steps_started_under_the_previous_sh_update": int(steppipe.steps_carried) if use_pipeline else 0,
         "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
         "host_ms_per_view": None if host_ms_per_view is None else round(host_ms_per_view, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "replicas_identical": replicas_identical, "param_digest": param_digest,

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 500 /* 0.5.0 (round 5: fdgs_forward_out.sparse_lists).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+#define FDGS_VERSION 501 /* 0.5.1 (round 5: fdgs_forward_out.sparse_lists, .colour_stream).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
                             (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
                             FDGS_VERSION: a binding built against another revision of this header is turned away instead of
                             having the library read past the end of a shorter struct. */
@@ -170,6 +170,12 @@ typedef struct fdgs_forward_out
 	                         (t * cap, t * cap + n_t) instead of the reference's prefix sums (identifyTileRanges), num_rendered (reported
 	                         lazily) is the same sum.  A list that outgrows cap is cut and the forward reported as failed, like any lazy
 	                         forward that does not fit.  Costs address space: T * cap entries of 12 bytes instead of num_rendered. */
+	void* colour_stream;  /* with split_colour = 1: NULL = the library's own second stream; otherwise the hipStream_t the SH -> RGB
+	                         launch goes onto (after an event of the geometry launch; the caller's stream waits for its event before the
+	                         blend).  Everything already enqueued on that stream comes first -- so a caller whose optimizer updates the
+	                         SH coefficients on it gets: geometry, binning and sort of the next view (which read no SH coefficient) next
+	                         to that update on the call's stream, the colours right behind it (fdgs.pipeline.StepPipeline, the first view
+	                         of a step).  Same device as the call's stream */
 } fdgs_forward_out;
 
 /* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output

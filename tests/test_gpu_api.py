@@ -576,6 +576,54 @@ def test_step_pipeline_lazy_equals_waiting_and_redoes_an_overflowing_step(gpu_de
     assert (perr > 2e-3).float().mean().item() <= 2e-3 and perr.max().item() <= 0.25   # (Adam on float-atomics noise: see above)
 
 
+def test_step_pipeline_overlap_steps_equals_plain(gpu_device):
+    """StepPipeline(overlap_steps=True): the SH coefficients' update of step k on a third stream, geometry + binning + sort of step
+    k + 1's first view next to it, that view's colours behind it (fdgs_forward_out.colour_stream).  Same kernels on the same numbers:
+    losses and parameters follow the plain pipeline's (to the float-atomics noise two runs of the SAME pipeline differ by).  A model
+    modified through torch between two steps is noticed (the version counter), one modified behind torch's back needs barrier()."""
+    from fdgs import train_host
+    from fdgs.pipeline import StepPipeline
+    cfg = synth.SceneConfig("ovs", 90012, 320, 240, 3, 2, 0.012, 10.0, True, 4, False)     # 13 M SH coefficients: an update of ~30 us
+    scene = synth.make_scene(cfg, seed=6, pose="rig1")
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    pipe = train_host.PipelineFlags()
+    B, steps = 3, 8
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / B * scene["time_duration"]) for b in range(B)]
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(gpu_device) for _ in range(B)]
+    runs = {}
+    for mode in ("plain", "overlap", "plain again"):
+        m = train_host.GaussianParams(scene, gpu_device)
+        opt = train_host.make_optimizer(m)
+        sp = StepPipeline(m, opt, world_size=1, lambda_dssim=0.2, overlap_steps=mode == "overlap")
+        assert sp.overlap_steps == (mode == "overlap")
+        losses = []
+        for k in range(steps):
+            if k == 3:     # through torch: seen without being told
+                with torch.no_grad():
+                    m.params["_opacity"].mul_(0.98)
+            if k == 5:     # behind torch's back (what a bench's restore does): the caller says so
+                m.flat.data[: m.P * 3].add_(1e-4)
+                sp.barrier()
+            _res, ls = sp.step(cams, gts, pipe, bg)
+            losses += [float(l) for l in ls]
+        torch.cuda.synchronize()
+        runs[mode] = (m.flat.detach().clone(), losses, sp.steps_carried, opt.exp_avg.clone())
+    # steps 1, 2, 4, 6, 7 start under the previous step's SH update; 0 (nothing before it), 3 and 5 wait for the caller's stream
+    assert runs["overlap"][2] == steps - 3 and runs["plain"][2] == 0, (runs["overlap"][2], runs["plain"][2])
+    np.testing.assert_allclose(runs["overlap"][1][:B], runs["plain"][1][:B], rtol=1e-6, atol=1e-7)      # first step: identical inputs
+    noise = (runs["plain again"][0] - runs["plain"][0]).abs()
+    for other in ("overlap",):
+        np.testing.assert_allclose(runs[other][1], runs["plain"][1], rtol=2e-5, atol=1e-6)
+        perr = (runs[other][0] - runs["plain"][0]).abs()
+        # (Adam on float-atomics noise: a parameter whose gradient is noise around zero may move by 2 lr per step either way; the bar is
+        # what two runs of the plain pipeline differ by, with room)
+        assert (perr > 2e-3).float().mean().item() <= max(2e-3, 4.0 * (noise > 2e-3).float().mean().item()), (perr > 2e-3).float().mean().item()
+        assert perr.max().item() <= max(0.25, 2.0 * noise.max().item())
+        merr = (runs[other][3] - runs["plain"][3]).abs().max().item()
+        assert merr <= 10.0 * max((runs["plain again"][3] - runs["plain"][3]).abs().max().item(), 1e-7), merr
+
+
 def test_backward_without_the_per_view_outputs(gpu_device):
     """fdgs_backward_out.dL_dcolors / dL_dcov3D / dL_dflows = NULL (``per_view_outputs=False``, what StepPipeline passes): the three
     slots come back as None, everything else -- dL_dmeans2D and every parameter gradient -- is what the full call writes (the two
