@@ -51,19 +51,19 @@ namespace fdgs
 	}
 
 	struct BlockId { int tile, sub; };
-	// Workgroup id -> (tile, 8x8 sub-block).  Workgroups are dealt round-robin to the 8 XCDs
-	// (id % 8); give each XCD a contiguous band of tiles and keep the 4 sub-blocks of a tile on
-	// one XCD so the shared list and records stay in one L2.  Inside its band an XCD takes the tiles in the order the scan
-	// kernel left in `order` -- longest lists first, so that the launch ends on short tiles instead of on whatever tile
-	// happens to come last (the ramp-down of a 21 760-workgroup launch was ~10 % of its duration); NULL: index order.
+	// Workgroup id -> (tile, 8x8 sub-block).  Workgroups are dealt round-robin to the 8 XCDs (id % 8): the 4 sub-blocks of a tile stay on
+	// one XCD (the shared list and records in one L2), and position p of the tile order goes to XCD p % 8.  `order` (tilebin.hip,
+	// tile_order_block) lists ALL tiles longest-first, so every XCD gets the same share of the long and the short lists and ends its
+	// part of the launch on short tiles (the ramp-down of a 21 760-workgroup launch in index order was ~10 % of its duration; with the
+	// longest-first order inside a contiguous eighth of the tiles per XCD -- rounds 2-4 -- the XCDs' unequal shares of the scene cost
+	// the blend kernels another 16 % on the bench's cameras); NULL: index order, dealt out the same way.
 	__device__ __forceinline__ BlockId block_of(int wg, int ntiles, const uint32_t* __restrict__ order)
 	{
-		const int chunk = (ntiles + NUM_XCDS - 1) / NUM_XCDS;
 		const int xcd = wg % NUM_XCDS, k = wg / NUM_XCDS;
 		BlockId b;
-		b.tile = xcd * chunk + (k >> 2); // may be >= ntiles for the last XCD: caller returns
 		b.sub = k & 3;
-		if (order != nullptr && b.tile < ntiles) b.tile = (int)order[b.tile];
+		const int p = (k >> 2) * NUM_XCDS + xcd;   // may be >= ntiles at the end of the grid: the caller returns
+		b.tile = (order != nullptr && p < ntiles) ? (int)order[p] : p;
 		return b;
 	}
 	static inline int blend_grid(int ntiles) { return div_up(ntiles, NUM_XCDS) * NUM_XCDS * 4; }

@@ -62,8 +62,8 @@ namespace fdgs
 		size_t final_T, n_contrib, ranges;
 		size_t tile_counters;   // [T] instance counts -> exclusive starts -> ends (count / scan / scatter passes)
 		size_t bin_ctl;         // { R, longest tile list } written by the scan, read back by the host
-		size_t tile_order;      // [T] the order in which the blend kernels take the tiles (longest lists first inside every XCD's
-		                        // band of tiles), written by one workgroup of the scatter launch from the
+		size_t tile_order;      // [T] the order in which the blend kernels take the tiles (all tiles, longest lists first; position p
+		                        // goes to XCD p % 8), written by one workgroup of the scatter launch from the
 		                        // [T] counts the scan leaves behind it (tile_order_counts_off); [T] words of scratch behind those
 		size_t total;
 	};

@@ -85,40 +85,38 @@ namespace fdgs
 		}
 	}
 
-	// Order of the tiles for the blend kernels (blend_common.h, block_of): inside every XCD's band of `band` consecutive tiles the
-	// longest lists go first, so that a blend launch ends on short tiles -- a counting sort over ORDER_BUCKETS length classes of the
-	// longest list (class 0 = the longest); the rank of a tile inside its class is whatever the LDS atomic hands out (the order only
-	// schedules work, no result depends on it).  Run by ONE extra workgroup of the scatter launch (off the forward's critical path:
-	// the scan only leaves a copy of the tile counts, which this workgroup turns into ranks in place).
+	// Order of the tiles for the blend kernels and the per-tile sort (blend_common.h, block_of): ONE order over all tiles, longest lists
+	// first -- position p of it goes to XCD p % 8 (workgroups are dealt round-robin to the XCDs), so that every XCD gets the same
+	// share of the long and of the short lists and inside an XCD the launch ends on short tiles.  A counting sort over ORDER_BUCKETS
+	// length classes of the longest list (class 0 = the longest); the rank of a tile inside its class is whatever the LDS atomic
+	// hands out (the order only schedules work, no result depends on it).  Rounds 2-4 gave every XCD a contiguous eighth of the tiles
+	// in row-major order (a band of tile rows, for its L2) with the longest-first order inside the band: the XCDs' shares of the WORK
+	// then are the bands' shares of the scene -- on the bench's cameras the blend kernels ran 16 % longer than with the work dealt out
+	// evenly (round 5, profiles/HISTORY.md; runs of 1 ... 85 tiles dealt round-robin and this global order are within 1 % of each other:
+	// which XCD's L2 a tile's records pass through does not matter).
+	// Run by ONE extra workgroup of the scatter launch (off the forward's critical path: the scan only leaves a copy of the tile counts)
+	// or, with sparse lists, of the sort launch.
 	// counts: [T] list lengths (left alone: a scatter pass that is launched a second time orders again); tmp: [T] scratch; order: [T];
-	// s_cls: 8 * ORDER_BUCKETS words of LDS.
+	// s_cls: ORDER_BUCKETS words of LDS.  T < 2^24 (the launchers check).
 	constexpr int NUM_XCDS_BIN = 8;     // blend_common.h NUM_XCDS
-	constexpr int ORDER_BUCKETS = 64;   // = WAVE: one wave scans the classes of a band
-	__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tmp, int T, int band, uint32_t gmax,
+	constexpr int ORDER_BUCKETS = 64;   // = WAVE: one wave scans the classes
+	__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tmp, int T, uint32_t gmax,
 	                                                 uint32_t* __restrict__ order, uint32_t* s_cls)
 	{
 		const int nthreads = (int)blockDim.x, lane = threadIdx.x & 63;
-		for (int k = threadIdx.x; k < 8 * ORDER_BUCKETS; k += nthreads) s_cls[k] = 0u;
+		for (int k = threadIdx.x; k < ORDER_BUCKETS; k += nthreads) s_cls[k] = 0u;
 		__syncthreads();
 		const float cls_scale = (float)ORDER_BUCKETS / ((float)gmax + 1.0f);
-		const float inv_band = 1.0f / (float)band;
-		const auto band_of = [&](int t) {
-			int b = (int)((float)t * inv_band);   // t / band by a float reciprocal and one correction step either way (b < 8)
-			if (b * band > t) b--;
-			else if ((b + 1) * band <= t) b++;
-			return b;
-		};
 		for (int t = threadIdx.x; t < T; t += nthreads)
 		{
 			const uint32_t cls = (uint32_t)(ORDER_BUCKETS - 1) - min((uint32_t)(ORDER_BUCKETS - 1), (uint32_t)((float)counts[t] * cls_scale));
-			const uint32_t rank = atomicAdd(&s_cls[band_of(t) * ORDER_BUCKETS + cls], 1u);
+			const uint32_t rank = atomicAdd(&s_cls[cls], 1u);
 			tmp[t] = (cls << 24) | rank;   // read back below by this same thread
 		}
 		__syncthreads();
-		for (int k = threadIdx.x; k < 8 * ORDER_BUCKETS; k += nthreads)   // whole waves (the workgroup has 256 or 1024 threads)
+		if (threadIdx.x < ORDER_BUCKETS)   // the first wave: exclusive scan of the class sizes (lane = class)
 		{
-			// exclusive scan of the class sizes of band k / 64 by one wave (lane = class)
-			const uint32_t n = s_cls[k];
+			const uint32_t n = s_cls[threadIdx.x];
 			uint32_t inc = n;
 #pragma unroll
 			for (int o = 1; o < WAVE; o <<= 1)
@@ -126,14 +124,13 @@ namespace fdgs
 				const uint32_t u = __shfl_up(inc, o);
 				if (lane >= o) inc += u;
 			}
-			s_cls[k] = inc - n;
+			s_cls[threadIdx.x] = inc - n;
 		}
 		__syncthreads();
 		for (int t = threadIdx.x; t < T; t += nthreads)
 		{
 			const uint32_t cr = tmp[t];
-			const int b = band_of(t);
-			order[b * band + s_cls[b * ORDER_BUCKETS + (cr >> 24)] + (cr & 0xFFFFFFu)] = (uint32_t)t;
+			order[s_cls[cr >> 24] + (cr & 0xFFFFFFu)] = (uint32_t)t;
 		}
 	}
 
@@ -143,14 +140,14 @@ namespace fdgs
 	                                                             int grid_x, int T, int rounds /* batch = rounds * BIN_T Gaussians per workgroup */,
 	                                                             uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
 	                                                             const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                             uint32_t* __restrict__ order /* [3 T + 16] or NULL */, int band,
+	                                                             uint32_t* __restrict__ order /* [3 T + 16] or NULL */,
 	                                                             uint32_t sparse_cap /* 0, or SPARSE lists: tile t's list lives at [t * sparse_cap, (t + 1) * sparse_cap) */)
 	{
-		extern __shared__ uint32_t s_hist[];   // max(T, 8 * ORDER_BUCKETS) words
+		extern __shared__ uint32_t s_hist[];   // max(T, ORDER_BUCKETS) words
 		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
 		{
 			// the extra workgroup of the scatter launch: the blend kernels' tile order from the scan's copy of the counts
-			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, band, ctl[1], order, s_hist);
+			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, ctl[1], order, s_hist);
 			return;
 		}
 		// launched before the host knew num_rendered (capi.hip): `pairs` holds `capacity` instances -- more than that: leave everything alone
@@ -220,12 +217,12 @@ namespace fdgs
 	__global__ void __launch_bounds__(256) tile_bin_direct_kernel(const ushort4* __restrict__ rect, const float* __restrict__ depths, int P,
 	                                                              int grid_x, uint32_t* __restrict__ counters, uint2* __restrict__ pairs,
 	                                                              const uint32_t* __restrict__ ctl, uint32_t capacity,
-	                                                              uint32_t* __restrict__ order, int T, int band, uint32_t sparse_cap)
+	                                                              uint32_t* __restrict__ order, int T, uint32_t sparse_cap)
 	{
-		__shared__ uint32_t s_cls[8 * ORDER_BUCKETS];
+		__shared__ uint32_t s_cls[ORDER_BUCKETS];
 		if (SCATTER && order != nullptr && blockIdx.x == gridDim.x - 1)
 		{
-			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, band, ctl[1], order, s_cls);
+			tile_order_block(order + tile_order_counts_off(T), order + tile_order_tmp_off(T), T, ctl[1], order, s_cls);
 			return;
 		}
 		if (SCATTER && sparse_cap == 0u && ctl[0] > capacity) return;
@@ -634,15 +631,15 @@ namespace fdgs
 	}
 
 	// The main instance (n_lo == 0: every tile, also writes `ranges`): workgroup b takes ONE tile -- with `order` (the blend kernels'
-	// tile order, written by the scatter launch: inside every XCD's band of tiles the longest lists first) slot (b % 8) * band + b / 8
-	// of it, so that the long lists start first and the launch ends on short ones; without: tile b.
+	// tile order, written by the scatter launch: all tiles, the longest lists first) entry b of it, so that the long lists start first
+	// -- dealt round-robin to the XCDs, as the workgroups are -- and the launch ends on short ones; without: tile b.
 	template <int THREADS, int ITEMS>
 	__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t* __restrict__ list_end, const uint2* __restrict__ pairs,
 	                                                           uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
 	                                                           u64* __restrict__ big_scratch, int n_lo /* handle lists longer than this */,
 	                                                           int lds_cap, int rank_max, const uint32_t* __restrict__ ctl, uint32_t capacity,
 	                                                           int last /* no further instance takes what this one leaves */,
-	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T, int band,
+	                                                           const uint32_t* __restrict__ order /* [T] or NULL */, int T,
 	                                                           uint32_t sparse_cap, uint32_t* __restrict__ report_ctl /* sparse main instance: ctl (written) */,
 	                                                           uint32_t* __restrict__ report_box, uint32_t ticket, uint32_t* __restrict__ order_out)
 	{
@@ -652,7 +649,7 @@ namespace fdgs
 			// SPARSE lists, the extra workgroup of the main instance: what the scan kernel does for compact lists -- num_rendered and the
 			// longest list from the tiles' counts (final since the scatter launch) into ctl and the caller's mailbox, and the blend
 			// kernels' tile order
-			__shared__ uint32_t s_rep[8 * ORDER_BUCKETS];
+			__shared__ uint32_t s_rep[ORDER_BUCKETS];
 			__shared__ uint32_t s_sum[THREADS / WAVE], s_max[THREADS / WAVE];
 			uint32_t sum = 0u, mx = 0u;
 			for (int t = threadIdx.x; t < T; t += THREADS) { const uint32_t c = list_end[t]; sum += c; mx = max(mx, c); }
@@ -672,18 +669,12 @@ namespace fdgs
 					__hip_atomic_store(&report_box[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 				}
 			}
-			if (order_out != nullptr) tile_order_block(list_end, order_out + tile_order_tmp_off(T), T, band, gmax, order_out, s_rep);
+			if (order_out != nullptr) tile_order_block(list_end, order_out + tile_order_tmp_off(T), T, gmax, order_out, s_rep);
 			return;
 		}
 		const int wg = (int)blockIdx.x - (report_ctl != nullptr ? 1 : 0);
-		int tile = wg;
-		if (order != nullptr)
-		{
-			const int slot = (wg % NUM_XCDS_BIN) * band + wg / NUM_XCDS_BIN;
-			if (wg / NUM_XCDS_BIN >= band || slot >= T) return;
-			tile = (int)order[slot];
-		}
-		else if (tile >= T) return;
+		if (wg >= T) return;
+		const int tile = order != nullptr ? (int)order[wg] : wg;
 		// launched before the host knew num_rendered: if the buffers are too small the scatter pass did not run either (the counters
 		// are not list ends) -- every tile is reported empty, so that whatever is queued behind reads nothing, and the host starts over
 		if (sparse_cap == 0u && ctl[0] > capacity)
@@ -707,8 +698,7 @@ namespace fdgs
 		if (P <= 0) return hipSuccess;
 		const ushort4* r4 = reinterpret_cast<const ushort4*>(rect);
 		uint2* p2 = reinterpret_cast<uint2*>(pairs);
-		const int band = div_up(T, NUM_XCDS_BIN);   // = the tiles per XCD of blend_common.h, block_of
-		if (band >= (1 << 24)) order = nullptr;
+		if (T >= (1 << 24)) order = nullptr;   // (tile_order_block packs a rank into 24 bits)
 		const int extra = (SCATTER && order) ? 1 : 0;   // one more workgroup: tile_order_block
 		if (T <= BIN_LDS_MAX_TILES)
 		{
@@ -726,11 +716,11 @@ namespace fdgs
 			}
 			const int rounds = bin_rounds(T);
 			hipLaunchKernelGGL(tile_bin_lds_kernel<SCATTER>, dim3(div_up(P, rounds * BIN_T) + extra), dim3(BIN_T),
-			                   (size_t)max(T, 8 * ORDER_BUCKETS) * 4, stream, r4, depths, P, grid_x, T, rounds, counters, p2, ctl, capacity, order, band, sparse_cap);
+			                   (size_t)max(T, ORDER_BUCKETS) * 4, stream, r4, depths, P, grid_x, T, rounds, counters, p2, ctl, capacity, order, sparse_cap);
 		}
 		else
 			hipLaunchKernelGGL(tile_bin_direct_kernel<SCATTER>, dim3(div_up(P, 256) + extra), dim3(256), 0, stream, r4, depths, P, grid_x, counters, p2,
-			                   ctl, capacity, order, T, band, sparse_cap);
+			                   ctl, capacity, order, T, sparse_cap);
 		return hipGetLastError();
 	}
 
@@ -769,7 +759,6 @@ namespace fdgs
 	                                 hipStream_t stream, uint32_t sparse_cap = 0u, uint32_t* report_ctl = nullptr, uint32_t* report_box = nullptr,
 	                                 uint32_t ticket = 0u, uint32_t* order_out = nullptr)
 	{
-		const int band = div_up(T, NUM_XCDS_BIN);
 		const size_t lds = (size_t)cap * 8 + TS_PAD * 4;
 		if (lds > 48 * 1024)
 		{
@@ -786,8 +775,8 @@ namespace fdgs
 				if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
 			}
 		}
-		hipLaunchKernelGGL((tile_sort_kernel<THREADS, ITEMS>), dim3((order ? band * NUM_XCDS_BIN : T) + (report_ctl ? 1 : 0)), dim3(THREADS), lds, stream,
-		                   counters, pairs, point_list, ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0, order, T, band,
+		hipLaunchKernelGGL((tile_sort_kernel<THREADS, ITEMS>), dim3(T + (report_ctl ? 1 : 0)), dim3(THREADS), lds, stream,
+		                   counters, pairs, point_list, ranges, big, n_lo, cap, rank_max, ctl, capacity, last ? 1 : 0, order, T,
 		                   sparse_cap, report_ctl, report_box, ticket, order_out);
 		return hipSuccess;
 	}

@@ -328,9 +328,9 @@ typedef struct fdgs_debug_view
 	const uint32_t* ranges;        /* [T,2]                                        */
 	const uint32_t* n_contrib;     /* [H*W]                                        */
 	const float* final_T;          /* [H*W]                                        */
-	const uint32_t* tile_order;    /* [T]   the order in which the blend kernels take the tiles: a permutation of every XCD's band
-	                                  of ceil(T / 8) consecutive tiles, longest lists first (64 length classes); written by one
-	                                  workgroup of the tile-scatter launch, so undefined for P == 0 */
+	const uint32_t* tile_order;    /* [T]   the order in which the blend kernels take the tiles: a permutation of all tiles,
+	                                  longest lists first (64 length classes), position p on XCD p % 8; written by one
+	                                  workgroup of the tile-scatter (sparse lists: sort) launch, so undefined for P == 0 */
 } fdgs_debug_view;
 int fdgs_debug_views(int32_t P, int32_t W, int32_t H, int32_t num_rendered,
                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,

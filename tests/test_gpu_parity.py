@@ -624,25 +624,27 @@ def test_split_colour_forward_is_bit_identical(cfg, gpu_device):
 
 @pytest.mark.parametrize("cfg", [SC("o1", 40000, 640, 480, 0, 0, 0.02, 1.0, True, 4, True), SC("o2", 3000, 100, 36, 0, 0, 0.03, 1.0, True, 4, True),
                                  SC("o3", 3000, 3104, 3104, 0, 0, 0.02, 1.0, True, 4, True)], ids=["1200-tiles", "21-tiles", "37636-tiles"])
-def test_tile_order_is_a_banded_longest_first_permutation(cfg, gpu_device):
-    """The order in which the blend kernels take the tiles (fdgs_debug_view.tile_order, written by the tile scan): a permutation
-    that keeps every tile inside its XCD's band of ceil(T / 8) consecutive tiles and puts longer lists first (64 length classes of
-    the longest list: monotone up to one class width)."""
+def test_tile_order_is_a_longest_first_permutation_dealt_evenly(cfg, gpu_device):
+    """The order in which the blend kernels take the tiles (fdgs_debug_view.tile_order, written by the tile scan): a permutation of ALL
+    tiles with the longer lists first (64 length classes of the longest list: monotone up to one class width); position p goes to XCD
+    p % 8 (blend_common.h, block_of), so the XCDs' shares of the instances differ by no more than a few lists -- whatever part of the
+    image the scene covers (rounds 2-4 gave every XCD a contiguous eighth of the tiles: its share of the work was that band's share of
+    the scene)."""
     scene = synth.make_scene(cfg, seed=21)
     hip, _ = run_hip(scene, gpu_device, None)
     order, rg = hip["tile_order"], hip["ranges"].astype(np.int64)
     T = rg.shape[0]
     assert order.shape == (T,) and np.array_equal(np.sort(order), np.arange(T))
     n = rg[:, 1] - rg[:, 0]
-    band = -(-T // 8)
     width = (int(n.max()) + 1) / 64.0 + 1.0
-    for b in range(8):
-        sl = order[b * band:min((b + 1) * band, T)]
-        if sl.size == 0:
-            continue
-        assert sl.min() >= b * band and sl.max() < min((b + 1) * band, T), "band %d leaks" % b
-        ln = n[sl]
-        assert (ln[:-1] + width >= ln[1:]).all(), "band %d is not longest-first" % b
+    ln = n[order]
+    assert (ln[:-1] + width >= ln[1:]).all(), "not longest-first"
+    share = np.array([int(ln[x::8].sum()) for x in range(8)])
+    # (one list more or less where 8 does not divide T, plus a class width per tile taken)
+    assert share.max() - share.min() <= n.max() + width * (-(-T // 8)) and share.max() - share.min() <= 0.02 * share.mean() + 2 * n.max(), share
+    # the contiguous bands of rounds 2-4 on this scene, for the record
+    band = -(-T // 8)
+    print("instances per XCD: dealt", share.tolist(), "contiguous bands", [int(n[b * band:(b + 1) * band].sum()) for b in range(8)])
     assert n.max() > 0
 
 
