@@ -70,6 +70,7 @@ class StepPipeline:
         # through torch (densification, reset_opacity: the version counter moves) is noticed and treated like barrier().
         self.overlap_steps = (bool(overlap_steps) and bool(overlap) and int(world_size) == 1 and bool(fuse_sh_adam)
                               and os.environ.get("FDGS_PIPELINE_OVERLAP_STEPS", "1") != "0")
+        self.finish_on_F = bool(overlap) and os.environ.get("FDGS_PIPELINE_LOSS_FINISH", "F") == "F"
         self._carry = None    # what the model looked like when the last step left its SH update running on stream A
         self.steps_carried = 0
         # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
@@ -166,7 +167,7 @@ class StepPipeline:
         if gather and (self._gathered is None or self._gathered.shape[0] != B or self._gathered.shape[2] != m.P):
             with torch.cuda.stream(self.sB):
                 self._gathered = torch.empty((B, self.world, m.P, 8), dtype=torch.float32, device=self.dev)
-        results, losses, keep = [], [], []
+        results, losses, keep, pend_loss = [], [], [], []
         R_last = -1
         sh_handle = []
         sh_gather = []     # gather: the work handles of the views' stage exchanges
@@ -193,6 +194,9 @@ class StepPipeline:
             with torch.cuda.stream(self.sB):
                 self.sB.wait_event(ev)
                 g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
+                if self.finish_on_F and b == B - 1:
+                    ev_parts = torch.cuda.Event()
+                    ev_parts.record(self.sB)   # every view's partial sums are there
                 if lazy and b == B - 1:
                     # the one look at the device per step: did every view's lists fit?  (the last forward's tile scan has usually run
                     # by now -- the host is about one view ahead of the device here, not inside every forward)
@@ -240,12 +244,20 @@ class StepPipeline:
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
                                      self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh,
                                      sh_stage=self._sh_stage[b] if defer_sh else None, per_view_outputs=False)
-                loss = l1_ssim_loss(loss_handle)   # the small reduction goes behind the backward, off the critical path
+                # the small reduction of the loss VALUE: behind the backward (nothing of the step waits for it) -- or, with two streams, all
+                # views' reductions on stream F behind its last forward (below): stream B's chain is the step's critical path, and 4 x ~6 us
+                # of a one-workgroup kernel were part of it
+                loss = None if self.finish_on_F else l1_ssim_loss(loss_handle)
+                pend_loss.append(loss_handle)
             # buffers allocated on F are read on B: keep them alive until F has waited for B (end of the step)
             keep.append((geom, binb, img, out_means3D, g_color, T))
             results.append({"render": color, "radii": radii, "depth": depth, "alpha_T": T, "flow": flow,
                             "viewspace_grad": grads[0], "num_rendered": R_last if (lazy and b == B - 1 and R < 0) else R})
             losses.append(loss)
+        if self.finish_on_F:
+            with torch.cuda.stream(self.sF):
+                self.sF.wait_event(ev_parts)
+                losses = [l1_ssim_loss(h) for h in pend_loss]
         self._optimizer_tail(rs, fuse, gather, sh_handle, sh_gather, sh_stepped)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)

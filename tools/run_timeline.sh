@@ -3,7 +3,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python $REPO/bench.py --steps 30 --warmup 10 --min-timed-ms 0 --cpu-samples 0 --dropin-steps 0 --host-cost-steps 0 --spatial-order-steps 0 --reflists-steps 0 --clustered-steps 0 "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python $REPO/bench.py --steps 30 --warmup 10 --min-timed-ms 0 --cpu-samples 0 --dropin-steps 0 --host-cost-steps 0 --spatial-order-steps 0 --reflists-steps 0 --clustered-steps 0 --axis-steps 0 --c5-steps 0 "$@" > $OUT/bench.log 2>&1
 cd $REPO
 CSV=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 echo "trace: $CSV"
