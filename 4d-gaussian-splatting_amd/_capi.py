@@ -84,7 +84,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_forward_lazy_status", "fdgs_rasterize_backward", "fdgs_preprocess_batch", "fdgs_sh_backward_batch", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_read",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_sample_every", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_l1_ssim_value_and_grad", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
@@ -138,6 +138,8 @@ def _load():
     lib.fdgs_sh_flush.restype = C.c_int
     lib.fdgs_profile_enable.argtypes = [C.c_int]
     lib.fdgs_profile_enable.restype = C.c_int
+    lib.fdgs_profile_sample_every.argtypes = [C.c_int32]
+    lib.fdgs_profile_sample_every.restype = C.c_int
     lib.fdgs_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.fdgs_profile_read.restype = C.c_int
     lib.fdgs_profile_reset.restype = C.c_int
@@ -337,9 +339,11 @@ def current_stream_handle(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def profile_enable(on: bool = True, stages=None):
+def profile_enable(on: bool = True, stages=None, every: int = 1):
     """Bracket stages with HIP events on the caller's stream (fdgs_profile_enable).  ``stages``: iterable of stage
-    names to restrict the events to (each event pair costs a few microseconds of device idle time)."""
+    names to restrict the events to; ``every``: only every n-th launch of a stage gets its event pair (fdgs_profile_sample_every: a
+    pair costs the stream ~13 us of idle time around the launch)."""
+    lib.fdgs_profile_sample_every(max(1, int(every)))
     if not on:
         mask = 0
     elif stages is None:

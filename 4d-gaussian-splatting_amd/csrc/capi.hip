@@ -47,6 +47,8 @@ namespace
 	};
 	// process-wide (autograd runs the backward on its own thread); guarded by g_prof_mu
 	std::atomic<uint32_t> g_prof_mask{0};   // bit i: stage i is bracketed with events
+	std::atomic<int> g_prof_every{1};       // ... every n-th launch of it (fdgs_profile_sample_every)
+	std::atomic<unsigned> g_prof_calls[FDGS_NUM_STAGES];
 	StageProf g_prof[FDGS_NUM_STAGES];
 	std::mutex g_prof_mu;
 
@@ -72,6 +74,8 @@ namespace
 		StageTimer(int stage, hipStream_t s) : stream(s)
 		{
 			if (!((g_prof_mask.load(std::memory_order_relaxed) >> stage) & 1u)) return;
+			const int every = g_prof_every.load(std::memory_order_relaxed);
+			if (every > 1 && g_prof_calls[stage].fetch_add(1u, std::memory_order_relaxed) % (unsigned)every != 0u) return;
 			g_prof_mu.lock();
 			locked = true;
 			p = &g_prof[stage];
@@ -99,6 +103,13 @@ namespace
 }
 
 extern "C" int fdgs_profile_enable(int stage_mask) { g_prof_mask.store((uint32_t)stage_mask); return FDGS_OK; }
+extern "C" int fdgs_profile_sample_every(int32_t n)
+{
+	if (n < 1) return FDGS_ERR_INVALID_ARG;
+	g_prof_every.store(n);
+	for (auto& c : g_prof_calls) c.store(0u);
+	return FDGS_OK;
+}
 extern "C" int fdgs_profile_reset(void)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);

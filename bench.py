@@ -47,6 +47,7 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or any(a == "--gpus" and i + 1 < l
 
 import torch  # noqa: E402
 
+PROFILE_EVERY = int(os.environ.get("FDGS_BENCH_PROFILE_EVERY", "5"))   # the dominant stage's live event pairs: every n-th launch
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 # Algorithmic HBM bytes per launch of each stage (BASELINE.md section 3 / SURVEY.md section 8d):
@@ -422,7 +423,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
             break
     restore()
     _capi.profile_reset()
-    _capi.profile_enable(True, stages=[dom])
+    _capi.profile_enable(True, stages=[dom], every=PROFILE_EVERY)
     torch.cuda.synchronize(dev)
     dbg = int(os.environ.get("FDGS_BENCH_DEBUG", "0"))     # 1: allocator / run-ahead statistics of the timed region; 2: + a synchronise per step
     if dbg:
@@ -463,7 +464,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, "C5"),
                         "traffic_source": "committed rocprofv3 --pmc passes of the same C5 step (profiles/pmc_traffic_r??_C5.json), not this run",
-                        "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"], "launches_timed": int(pd[1]),
+                        "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"], "launches_timed": int(pd[1]), "launches_bracketed": "every %d-th" % PROFILE_EVERY,
                         "algo_bytes_per_launch": int(dom_bytes)},
            "what": "BASELINE configs[4] (C5: %d Gaussians, %dx%d, SH degree %d, M = %d) through the same two-stream step as `value`, %d views per step; "
                    "stages: one single-stream step, HIP events per stage" % (P, W, H, cfg.sh_degree, M, B)}
@@ -652,7 +653,9 @@ def main():
     # Timed region (the two-stream pipeline): only the dominant kernel keeps its event pair -- the roofline figure is
     # measured live here -- and one event per step boundary on the main stream gives the per-step distribution.
     _capi.profile_reset()
-    _capi.profile_enable(True, stages=[dom])
+    # (every PROFILE_EVERY-th launch of it: an event pair costs the stream ~13 us of idle time around the launch -- 2 % of the step if
+    # every blend backward carried one; 5 is coprime to the 4 views of a step, so the samples rotate through the views)
+    _capi.profile_enable(True, stages=[dom], every=PROFILE_EVERY)
     _R_LOG.clear()
     # the timed region: --steps steps, repeated (whole multiples) until it lasts >= --min-timed-ms
     torch.cuda.synchronize(dev)
@@ -1056,7 +1059,7 @@ def main():
                 "traffic_source": ("committed rocprofv3 --pmc passes of the same step (profiles/pmc_traffic_r*.json: tools/collect_profiles.sh, "
                                    "tools/pmc_traffic.py), not this run" if cfg.name in ("C3", "C5") else None),
                 "avg_kernel_ms": round(dom_ms, 4), "avg_kernel_ms_single_stream": stages[dom]["ms"],
-                "launches_timed": int(prof_dom[1]), "algo_bytes_per_launch": int(dom_bytes),
+                "launches_timed": int(prof_dom[1]), "launches_bracketed": "every %d-th" % PROFILE_EVERY, "algo_bytes_per_launch": int(dom_bytes),
                 "note": "the blend kernels are VALU-issue-bound, not HBM-bound (DESIGN.md section 4): the fraction of the HBM "
                         "peak is reported as the contract asks; valu_issue_frac = VALU issue cycles per SIMD (SQ counters, "
                         "profiles/) / kernel cycles at the shader clock measured under the step's load is the bound this kernel actually runs against"}

@@ -381,6 +381,11 @@ void fdgs_debug_tile_sort_limits(int32_t lds_cap, int32_t rank_max);
 #define FDGS_STAGE_SH_BWD 10
 #define FDGS_NUM_STAGES 11
 int fdgs_profile_enable(int stage_mask); /* bit i set: bracket stage i with HIP events; 0 = off, -1 = all stages */
+int fdgs_profile_sample_every(int32_t n); /* n >= 1: only every n-th launch of a bracketed stage gets its event pair (default 1: every
+                                             launch).  An event pair costs its stream ~13 us of idle time around the launch (measured: a
+                                             6-7 us gap in front of and behind every bracketed blend backward in the kernel trace); a caller
+                                             that measures a stage INSIDE a timed region samples it -- n coprime to the views per step, so
+                                             that the samples rotate through the views */
 int fdgs_profile_read(int stage, double* total_ms, int64_t* samples);
 int fdgs_profile_reset(void);
 const char* fdgs_stage_name(int stage);
