@@ -25,6 +25,7 @@ Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the field definitions).
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -350,6 +351,22 @@ def new_pipeline(*a, **kw):
     return p
 
 
+def warm_up(step_fn, dev, world=1, at_least=3, at_most=10):
+    """Untimed steps in front of a timed leg, until the caller's allocator is quiet: the host runs up to a mailbox ring of forwards ahead
+    of the device and every forward in flight holds its binning buffer (C3-clustered: 570 MB, C5: 656 MB with sparse lists) -- that
+    depth, hence the last device allocations (tens of ms each on a busy GPU: a leg of 6-10 steps that contained four of them read
+    half its rate), is only reached after three or four steps.  Several ranks: a fixed number (a step holds collectives)."""
+    gc.collect()   # (the collector is off during the legs: bench.py main)
+    for k in range(at_most):
+        n0 = torch.cuda.memory_stats(dev)["num_device_alloc"]
+        step_fn()
+        if world > 1:
+            if k + 1 >= at_least + 2:
+                break
+        elif k + 1 >= at_least and torch.cuda.memory_stats(dev)["num_device_alloc"] == n0:
+            break
+
+
 def models_touched():
     """The bench has written parameters / optimizer state through torch on its own stream (the restores between legs and repetitions):
     a StepPipeline(overlap_steps=True) starts its next step only behind that (StepPipeline.barrier)."""
@@ -413,14 +430,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
     dom = max((k for k in prof if k != "readback"), key=lambda k: prof[k][0])
     sp2 = new_pipeline(model, opt, overlap=not args.no_overlap, overlap_steps=not args.no_overlap_steps, **kw)
     restore()
-    # warm-up until the caller's allocator is quiet: the host runs up to a mailbox ring of forwards ahead of the device, and every
-    # forward in flight holds a binning buffer (656 MB each here) -- the depth, hence the last device allocations (tens of ms each
-    # on a busy GPU), is only reached after three or four steps
-    for k in range(8):
-        n0 = torch.cuda.memory_stats(dev)["num_device_alloc"]
-        sp2.step(cams, gts, pipe, bg)
-        if k >= 2 and torch.cuda.memory_stats(dev)["num_device_alloc"] == n0:
-            break
+    warm_up(lambda: sp2.step(cams, gts, pipe, bg), dev)
     restore()
     _capi.profile_reset()
     _capi.profile_enable(True, stages=[dom], every=PROFILE_EVERY)
@@ -691,7 +701,6 @@ def main():
     torch.cuda.synchronize(dev)
     # no collector pauses inside the timed region (the host runs ~1.8 ms ahead of the GPU per step; a generation-2 collection of the
     # step's many small Python objects takes longer than that)
-    import gc
     gc.collect()
     gc.disable()
     if use_pipeline and world > 1:
@@ -722,7 +731,10 @@ def main():
         print("step dbg: event pairs (ms)", [round(starts[i].elapsed_time(ends[i]), 2) for i in range(min(steps_timed, 45))], file=sys.stderr)
         print("step dbg: gaps between pairs (ms)", [round(ends[i].elapsed_time(starts[i + 1]), 2) for i in range(min(steps_timed - 1, 45))], file=sys.stderr)
         print("step dbg: host (ms)", [round(h, 2) for h in _host_ms[:45]], file=sys.stderr)
-    gc.enable()
+    # (the collector stays off for the rest of the run -- every leg below is a few dozen steps, i.e. tens of milliseconds, and one
+    # generation-2 pause of the interpreter in it is 20-40 % of its reading: legs that read 1000-1400 where the next run read 1700;
+    # warm_up() collects by hand in front of every leg)
+    gc.collect()
     _capi.profile_enable(False)
     shader_ghz = pair_ghz = None
     try:
@@ -738,7 +750,6 @@ def main():
         # read 1.5 % less) on the same steps right behind the timed region, through a pipeline without overlap_steps: three streams + the
         # sampler's = the four hardware queues
         try:
-            gc.disable()
             cpipe = new_pipeline(model, opt, world_size=world, lambda_dssim=0.2, overlap=not args.no_overlap,
                                  gather_max_views=0 if args.dense_sh_exchange else 32, split_colour=args.split_colour == "all",
                                  tile_cull=not args.no_tile_cull, batch_views=args.batch_views, sh_group=args.sh_group, lazy=not args.no_lazy,
@@ -758,7 +769,6 @@ def main():
         except Exception:
             shader_ghz = pair_ghz
         finally:
-            gc.enable()
             restore()
     prof_dom = _capi.profile_read()[dom]
     # N > 1: every rank's own wall time per step and the exchange time nothing overlapped (the sum of stream B's waits for a
@@ -874,17 +884,23 @@ def main():
                           gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy, sparse_lists=False,
                           overlap_steps=not args.no_overlap_steps)
         restore()
-        for _ in range(3):
-            rp.step(cams, gts, pipe, bg)
+        warm_up(lambda: rp.step(cams, gts, pipe, bg), dev, world)
         torch.cuda.synchronize(dev)
         barrier(world)
+        r_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reflists_steps)]
         tr0 = time.perf_counter()
-        for _ in range(args.reflists_steps):
+        for i in range(args.reflists_steps):
+            r_ev[i][0].record()
             rres, _l = rp.step(cams, gts, pipe, bg)
+            r_ev[i][1].record()
         torch.cuda.synchronize(dev)
         barrier(world)
         dtr = max_over_ranks(time.perf_counter() - tr0, world, dev)
+        r_ms = sorted(a.elapsed_time(b) for a, b in r_ev)
         reflists = {"images_s": round(world * B * args.reflists_steps / dtr, 2), "ms_per_step": round(dtr / args.reflists_steps * 1e3, 4),
+                    # (this leg reads 1100-1200 instead of 1650-1700 in about every third run of the full line -- a few steps of several times the
+                    # usual length, cause not found; the median step is the same either way)
+                    "images_s_median_step": round(world * B / (r_ms[len(r_ms) // 2] * 1e-3), 2), "ms_per_step_max": round(r_ms[-1], 4),
                     "steps": args.reflists_steps, "num_rendered": int(round(sum(r["num_rendered"] for r in rres) / len(rres))),
                     "what": "the same step with tile_cull = 0 and sparse_lists = 0: point_list / ranges / n_contrib are the reference's, bit for bit (tests/test_gpu_parity.py)"}
         del rp
@@ -902,8 +918,7 @@ def main():
             restore()
             train_host.spatial_sort(model, opt)
             models_touched()
-        for _ in range(3):
-            step()
+        warm_up(step, dev, world)
         torch.cuda.synchronize(dev)
         barrier(world)
         ts0 = time.perf_counter()
@@ -934,8 +949,7 @@ def main():
         which = "axis" if args.cameras == "rig" else "rig"
         ocams = make_cams(scene, which)
         restore()
-        for _ in range(3):
-            steppipe.step(ocams, gts, pipe, bg)
+        warm_up(lambda: steppipe.step(ocams, gts, pipe, bg), dev, world)
         restore()
         torch.cuda.synchronize(dev)
         barrier(world)
@@ -970,8 +984,7 @@ def main():
                           sparse_lists=not args.no_sparse_lists, overlap_steps=not args.no_overlap_steps)
         # (on the on-axis camera whatever --cameras says: the box is placed to project onto 15 % of THAT image, and the leg's full-size parity test uses it)
         ccams = [train_host.SyntheticCamera(cs, dev, timestamp=(b + 0.5) / B * cs["time_duration"]) for b in range(B)]
-        for _ in range(3):
-            cres, _l = cp.step(ccams, gts, pipe, bg)
+        warm_up(lambda: cp.step(ccams, gts, pipe, bg), dev)
         cm.flat.data.copy_(csnap[0]); co.exp_avg.copy_(csnap[1]); co.exp_avg_sq.copy_(csnap[2]); co.step_count = 0
         models_touched()
         torch.cuda.synchronize(dev)
