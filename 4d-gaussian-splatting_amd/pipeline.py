@@ -24,6 +24,9 @@ from .loss import l1_ssim_grad, l1_ssim_loss
 from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stage_begin, timed_wait
 
 
+_LAST_STEPPER = {}    # id(model) -> weak reference to the pipeline whose step() touched the model last (overlap_steps: see _model_token)
+
+
 class StepPipeline:
     def __init__(self, model, optimizer, world_size: int = 1, lambda_dssim: float = 0.2, overlap: bool = True,
                  fuse_sh_adam: bool = True, gather_max_views: int = 32, split_colour: bool = False, batch_views: bool = False,
@@ -121,7 +124,9 @@ class StepPipeline:
 
     def _model_token(self):
         m = self.model
-        return (id(m.flat), m.flat._version, m.P, m.flat.data_ptr())
+        last = _LAST_STEPPER.get(id(m))
+        # (another pipeline that stepped the same model in between counts as the caller having touched it)
+        return (id(m.flat), m.flat._version, m.P, m.flat.data_ptr(), last is not None and last() is self)
 
     def step(self, cams: Sequence, gts: Sequence[torch.Tensor], pipe, bg: torch.Tensor, scaling_modifier: float = 1.0):
         """Runs forward + loss + backward of every view, the gradient all-reduce and the optimizer step.
@@ -145,6 +150,8 @@ class StepPipeline:
         # wait for it.  B does: its first launch of the step is the first view's loss, behind that view's colours anyway
         carried = self.overlap_steps and self._carry is not None and self._carry == self._model_token()
         self._carry = None
+        import weakref
+        _LAST_STEPPER[id(m)] = weakref.ref(self)
         if carried:
             self.steps_carried += 1
         else:

@@ -580,7 +580,8 @@ def test_step_pipeline_overlap_steps_equals_plain(gpu_device):
     """StepPipeline(overlap_steps=True): the SH coefficients' update of step k on a third stream, geometry + binning + sort of step
     k + 1's first view next to it, that view's colours behind it (fdgs_forward_out.colour_stream).  Same kernels on the same numbers:
     losses and parameters follow the plain pipeline's (to the float-atomics noise two runs of the SAME pipeline differ by).  A model
-    modified through torch between two steps is noticed (the version counter), one modified behind torch's back needs barrier()."""
+    modified through torch between two steps is noticed (the version counter), and so is another pipeline that stepped the same model
+    in between; one modified behind torch's back needs barrier()."""
     from fdgs import train_host
     from fdgs.pipeline import StepPipeline
     cfg = synth.SceneConfig("ovs", 90012, 320, 240, 3, 2, 0.012, 10.0, True, 4, False)     # 13 M SH coefficients: an update of ~30 us
@@ -597,6 +598,7 @@ def test_step_pipeline_overlap_steps_equals_plain(gpu_device):
         opt = train_host.make_optimizer(m)
         sp = StepPipeline(m, opt, world_size=1, lambda_dssim=0.2, overlap_steps=mode == "overlap")
         assert sp.overlap_steps == (mode == "overlap")
+        other = StepPipeline(m, opt, world_size=1, lambda_dssim=0.2)     # a second pipeline on the same model (an evaluation loop, a bench leg)
         losses = []
         for k in range(steps):
             if k == 3:     # through torch: seen without being told
@@ -605,12 +607,14 @@ def test_step_pipeline_overlap_steps_equals_plain(gpu_device):
             if k == 5:     # behind torch's back (what a bench's restore does): the caller says so
                 m.flat.data[: m.P * 3].add_(1e-4)
                 sp.barrier()
+            if k == 7:     # the other pipeline takes a step: seen without being told
+                other.step(cams, gts, pipe, bg)
             _res, ls = sp.step(cams, gts, pipe, bg)
             losses += [float(l) for l in ls]
         torch.cuda.synchronize()
         runs[mode] = (m.flat.detach().clone(), losses, sp.steps_carried, opt.exp_avg.clone())
-    # steps 1, 2, 4, 6, 7 start under the previous step's SH update; 0 (nothing before it), 3 and 5 wait for the caller's stream
-    assert runs["overlap"][2] == steps - 3 and runs["plain"][2] == 0, (runs["overlap"][2], runs["plain"][2])
+    # steps 1, 2, 4, 6 start under the previous step's SH update; 0 (nothing before it), 3, 5 and 7 wait for the caller's stream
+    assert runs["overlap"][2] == steps - 4 and runs["plain"][2] == 0, (runs["overlap"][2], runs["plain"][2])
     np.testing.assert_allclose(runs["overlap"][1][:B], runs["plain"][1][:B], rtol=1e-6, atol=1e-7)      # first step: identical inputs
     noise = (runs["plain again"][0] - runs["plain"][0]).abs()
     for other in ("overlap",):
