@@ -731,6 +731,10 @@ def main():
         print("step dbg: event pairs (ms)", [round(starts[i].elapsed_time(ends[i]), 2) for i in range(min(steps_timed, 45))], file=sys.stderr)
         print("step dbg: gaps between pairs (ms)", [round(ends[i].elapsed_time(starts[i + 1]), 2) for i in range(min(steps_timed - 1, 45))], file=sys.stderr)
         print("step dbg: host (ms)", [round(h, 2) for h in _host_ms[:45]], file=sys.stderr)
+        _ev = [starts[i].elapsed_time(ends[i]) for i in range(steps_timed)]
+        _med = sorted(_ev)[len(_ev) // 2]
+        print("step dbg: steps over twice the median (index, event ms, host ms)", [(i, round(_ev[i], 2), round(_host_ms[i], 2)) for i in range(steps_timed) if _ev[i] > 2 * _med],
+              "host-only outliers", [(i, round(_host_ms[i], 2)) for i in range(steps_timed) if _host_ms[i] > 3 * _med and _ev[i] <= 2 * _med], file=sys.stderr)
     # (the collector stays off for the rest of the run -- every leg below is a few dozen steps, i.e. tens of milliseconds, and one
     # generation-2 pause of the interpreter in it is 20-40 % of its reading: legs that read 1000-1400 where the next run read 1700;
     # warm_up() collects by hand in front of every leg)
@@ -1094,7 +1098,9 @@ def main():
         # same instruction count); the fraction with it is kept next to the other one
         single_ms = stages[dom]["ms"] if dom in stages else dom_ms
         valu["kernel_cycles"] = int(single_ms * 1e-3 * ghz * 1e9)
-        valu["kernel_cycles_from"] = "the kernel's single-stream duration in this run (stage pass, same views as the counter pass) x the clock measured in this run"
+        valu["kernel_cycles_from"] = ("the kernel's single-stream duration in this run (stage pass, same views as the counter pass) x the clock measured in this run; "
+                                      "a fraction a few percent above 1 is within the method's accuracy: SQ_ACTIVE_INST_VALU sums the cycles of the main and "
+                                      "the transcendental pipe (3.8 % of this kernel's VALU instructions), and the sampled clock averages over a loop of whole steps")
         valu["clock"] = ("measured under the step's load (s_memtime / s_memrealtime sampler, fdgs_debug_clock_sample; shader_clock_note)" if shader_ghz
                          else "2.4 GHz maximum clock assumed: valu_issue_frac is a LOWER bound")
         roofline["valu"] = valu
@@ -1114,6 +1120,7 @@ def main():
         "value_median": round(world * B * 1e3 / pct(0.5), 3),
         "ms_per_step": round(dt / steps_timed * 1e3, 4),
         "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4),
+        "ms_per_step_max": round(step_ms[-1], 4), "steps_over_twice_the_median": int(sum(1 for t_ in step_ms if t_ > 2.0 * pct(0.5))),
         "ms_per_image": round(dt / (steps_timed * B) * 1e3, 4),
         "lazy_forward": bool(use_pipeline and not args.no_lazy and world == 1), "lazy_steps_redone": lazy_redone,
         # fdgs_forward_out.sparse_lists: lazy forwards keep every tile's list at a fixed offset of the binning buffer (the same lists; no count /
