@@ -13,6 +13,7 @@ are written (view 0) / added (views 1..) straight into the flat bucket (``Gaussi
 pre-scaled by 1 / (B * world) so that the all-reduce SUM is already the mean.  Same arithmetic as
 ``render_raw`` + ``fused_l1_ssim`` + ``backward()`` per view (tests/test_gpu_api.py compares the two).
 """
+import weakref
 from typing import List, Sequence
 
 import torch
@@ -65,8 +66,8 @@ class StepPipeline:
         # is the last thing of a step -- but geometry, binning and sort of the next step's first view read no SH coefficient.  The SH
         # update goes onto a third stream A; the first view of the next step is a split_colour forward whose colour launch goes onto A
         # as well (fdgs_forward_out.colour_stream: in order behind the update, no event), while its geometry + binning + sort run on
-        # stream F as soon as the GEOMETRY parameters' Adam step (23 us, stream B) is through.  Same kernels on the same numbers: the
-        # parameters after n steps are bit-identical with and without (tests/test_gpu_api.py).
+        # stream F as soon as the GEOMETRY parameters' Adam step (23 us, stream B) is through.  Same kernels on the same numbers: losses and
+        # parameters follow the plain pipeline's to the float-atomics noise two runs of ONE pipeline differ by (tests/test_gpu_api.py).
         # The promise: between two step() calls the caller enqueues nothing on ITS stream that writes the model / optimizer state or
         # that the next forwards depend on, and is done with the previous step's result tensors -- or it calls barrier() first (stream F
         # does not wait for the caller's stream at the start of such a step).  A model whose flat tensor was replaced or modified
@@ -150,7 +151,6 @@ class StepPipeline:
         # wait for it.  B does: its first launch of the step is the first view's loss, behind that view's colours anyway
         carried = self.overlap_steps and self._carry is not None and self._carry == self._model_token()
         self._carry = None
-        import weakref
         _LAST_STEPPER[id(m)] = weakref.ref(self)
         if carried:
             self.steps_carried += 1
