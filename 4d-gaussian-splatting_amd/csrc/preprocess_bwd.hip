@@ -61,7 +61,7 @@ namespace fdgs
 		return r;
 	}
 
-	__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const BwdArgs a)
+	__device__ __forceinline__ void preprocess_bwd_body(const BwdArgs& a)
 	{
 		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 		if (idx >= a.P) return;
@@ -365,6 +365,13 @@ namespace fdgs
 		if (a.dL_drot_r) reinterpret_cast<float4*>(a.dL_drot_r)[idx] = drot_r;
 	}
 
+	// Two builds of the same body: 132 VGPRs = three waves per SIMD, and -- for scenes of a million Gaussians and more -- held to 128
+	// VGPRs = four waves per SIMD at the price of three 8-byte spills.  Measured (round 5): C5 (2 M Gaussians) 151 -> 141 us, 4.2 TB/s
+	// algorithmic / 4.8 TB/s of counted traffic; C3 (300 k Gaussians, 1172 workgroups: launch and tail, not occupancy) 34.3 -> 34.4 us
+	// and the two-stream step 0.3 % slower, so small scenes keep the first one.
+	__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const BwdArgs a) { preprocess_bwd_body(a); }
+	__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_bwd_kernel_w4(const BwdArgs a) { preprocess_bwd_body(a); }
+
 	hipError_t launch_preprocess_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out,
 	                                 const char* geom, hipStream_t stream)
 	{
@@ -390,7 +397,8 @@ namespace fdgs
 		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
 		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;
 		a.dL_drot = out.dL_drotations; a.dL_drot_r = out.dL_drotations_r;
-		hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		if (s.P >= (1 << 20)) hipLaunchKernelGGL(preprocess_bwd_kernel_w4, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();
 	}
 }
