@@ -146,7 +146,7 @@ def camera_for(pose, W: int, H: int) -> Dict[str, object]:
 
 def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H: int = None,
                random_flow: bool = False, bg=(0.0, 0.0, 0.0), timestamp_frac: float = 0.5, pose="axis",
-               alloc=None) -> Dict[str, object]:
+               alloc=None, rot_sigma=0.05, st_scale: float = 1.0) -> Dict[str, object]:
     """Post-activation rasterizer inputs for ``cfg`` (CPU float32 tensors).
 
     ``pose``: a POSES name or a make_camera keyword dict (default: the unrotated on-axis camera).
@@ -154,6 +154,13 @@ def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H:
     scene/gaussian_model.py:65,92,222-228: M = 48 for (3, 2)) while the ACTIVE degrees stay cfg.sh_degree / cfg.sh_degree_t -- the
     state of the first 5000 iterations of every training run (one degree up every 1000 iterations, gaussian_model.py:253-257,
     train.py:93-94).  The coefficients beyond the active ones are non-zero on purpose: the kernels must not read them.
+
+    ``rot_sigma``: how far ``rotations`` / ``rotations_r`` are from the identity quaternion: normalize((1,0,0,0) + rot_sigma * N(0,1)^4)
+    (0.05 = SURVEY 8d's generator: within ~6 degrees of identity), or "uniform" = normalize(N(0,1)^4): uniformly distributed unit
+    quaternions, i.e. arbitrary orientations of the 3D ellipsoid and arbitrary 4D rotations M_l * M_r -- what a trained model holds
+    (scene/gaussian_model.py:191-197 only normalises).  The same number of draws either way: every other tensor of the scene is the same.
+    ``st_scale`` multiplies ``scales_t``: a general 4D rotation turns part of the temporal axis into space (cov_t = Sigma[3][3] shrinks to
+    ~ scales_t^2 * R[3][3]^2, forward.cu:332), so fewer Gaussians pass the 0.05 temporal cull at the same scales_t.
 
     Keys mirror GaussianRasterizer.forward's arguments
     (gaussian_renderer/diff_gaussian_rasterization.py:263-267) plus the settings.
@@ -181,9 +188,15 @@ def make_scene(cfg: SceneConfig, seed: int = 0, P: int = None, W: int = None, H:
     ts = (rand(P, 1) * 1.2 - 0.1) * dur
     scales = cfg.s0 * torch.exp(0.3 * randn(P, 3))
     scales_t = math.sqrt(0.2) * torch.exp(0.3 * randn(P, 1)) * dur
+    if st_scale != 1.0:
+        scales_t = scales_t * float(st_scale)
     ident = torch.tensor([1.0, 0.0, 0.0, 0.0])
-    rot = torch.nn.functional.normalize(ident + 0.05 * randn(P, 4), dim=1)
-    rot_r = torch.nn.functional.normalize(ident + 0.05 * randn(P, 4), dim=1)
+    if rot_sigma == "uniform":
+        rot = torch.nn.functional.normalize(randn(P, 4), dim=1)
+        rot_r = torch.nn.functional.normalize(randn(P, 4), dim=1)
+    else:
+        rot = torch.nn.functional.normalize(ident + float(rot_sigma) * randn(P, 4), dim=1)
+        rot_r = torch.nn.functional.normalize(ident + float(rot_sigma) * randn(P, 4), dim=1)
     opacity = torch.sigmoid(randn(P, 1))
     if alloc is None:
         M = num_sh_coeffs(cfg.sh_degree, cfg.sh_degree_t, cfg.force_sh_3d, cfg.gaussian_dim)

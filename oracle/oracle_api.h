@@ -134,7 +134,9 @@ int oracle_threads(void);
  *   0  the reference: fp32 atomicAdd per (pixel, contributor), tiles / threads of a block in index order;
  *   1  the same fp32 atomics with the tiles and the threads of a block visited in REVERSE order -- another legal execution
  *      order of the same CUDA kernel: 0 vs 1 is the reference's own accumulation-order noise (both oracles);
- *   2  (port oracle only; the verbatim build answers -1) the same terms accumulated in double, rounded to fp32 once.
+ *   2  (port oracle only; the verbatim build answers -1) the same terms accumulated in double, rounded to fp32 once;
+ *   3  (port oracle only) a conditioning probe: mode 2 with every term multiplied by (1 +- 1e-6), sign = hash(pixel, Gaussian, slot):
+ *      |mode 3 - mode 2| is what a few-ulp difference per term does to each Gaussian's gradients behind the covariance chain.
  * Returns 0, or -1 when the mode is not supported by this oracle. */
 int oracle_set_accumulation(int mode);
 

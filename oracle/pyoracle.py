@@ -262,7 +262,8 @@ def mark_visible(means3D, viewmatrix, projmatrix, kind="port"):
 
 def set_accumulation(mode, kind="port"):
     """oracle_set_accumulation (oracle_api.h): 0 = the reference's fp32 atomics in index order, 1 = the same atomics with tiles
-    and threads in reverse order (another legal execution order of the same kernel), 2 = double accumulation (port only)."""
+    and threads in reverse order (another legal execution order of the same kernel), 2 = double accumulation (port only),
+    3 = mode 2 with every term perturbed by a relative 1e-6 (port only: a conditioning probe, see oracle/fdgs_oracle.c)."""
     lib = _load(kind)
     lib.oracle_set_accumulation.argtypes = [C.c_int]
     lib.oracle_set_accumulation.restype = C.c_int

@@ -42,7 +42,17 @@ FIXTURES = {
     "dim3_sh2_rig0": (SC("g", 700, 100, 60, 2, 0, 0.04, 1.0, False, 3, False), 19, dict(random_flow=True, pose="rig0")),
     "rot4d_alloc48_deg10_rig1": (SC("g", 500, 88, 72, 1, 0, 0.05, 4.0, True, 4, False), 20, dict(pose="rig1", alloc=(3, 2), bg=(0.1, 0.0, 0.3))),
     "rot4d_alloc48_deg31_rig3": (SC("g", 500, 88, 72, 3, 1, 0.05, 4.0, True, 4, False), 21, dict(pose="rig3", alloc=(3, 2), random_flow=True)),
+    # round 6 -- ARBITRARY ORIENTATIONS: uniformly distributed unit quaternions for `rotations` (computeCov3D and its backward,
+    # forward.cu:242-276, backward.cu:621-684) and for the pair (`rotations`, `rotations_r`) of the 4D rotation M_r M_l
+    # (computeCov3D_conditional, forward.cu:279-352, backward.cu:689-834); every fixture before this one draws them within ~6 degrees
+    # of identity.  On rotated cameras.  The rot_4d ones with scales_t x 2 and the pairs whose splat is wider than 40 px / more
+    # elongated than 1:5 on screen redrawn (tests/util.py::bounded_footprint: the plain 1e-4 gradient bar applies to what is left)
+    "rot4d_sh3t1_uniform_rig1": (SC("g", 600, 96, 72, 3, 1, 0.05, 2.0, True, 4, False), 22, dict(pose="rig1", rot_sigma="uniform", st_scale=2.0, random_flow=True, bg=(0.2, 0.1, 0.4))),
+    "rot4d_sh3t2_uniform_rig0": (SC("g", 600, 96, 72, 3, 2, 0.05, 2.0, True, 4, False), 24, dict(pose="rig0", rot_sigma="uniform", st_scale=2.0)),
+    "dim3_sh2_uniform_rig3": (SC("g", 700, 100, 60, 2, 0, 0.04, 1.0, False, 3, False), 23, dict(pose="rig3", rot_sigma="uniform", random_flow=True)),
+    "dim4_norot_sh1_uniform_rig2": (SC("g", 700, 90, 70, 1, 0, 0.04, 1.0, False, 4, True), 25, dict(pose="rig2", rot_sigma="uniform", bg=(1.0, 1.0, 1.0))),
 }
+BOUNDED = ("rot4d_sh3t1_uniform_rig1", "rot4d_sh3t2_uniform_rig0")
 # scene-dict overrides applied after make_scene (the flags travel in the fixture as sc_scale_modifier / sc_prefilter_var)
 OVERRIDES = {
     "rot4d_sh1t1_mod07_pf02": dict(scale_modifier=0.7, prefilter_var=0.2),
@@ -59,6 +69,10 @@ def scene_for(name):
     cfg, seed, kw = FIXTURES[name]
     sc = synth.make_scene(cfg, seed=seed, **kw)
     sc.update(OVERRIDES.get(name, {}))
+    if name in BOUNDED:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import bounded_footprint
+        bounded_footprint(sc)
     return sc
 
 

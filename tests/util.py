@@ -244,3 +244,133 @@ def check_backward(hipg, refg, label="", tol=GRAD_TOL):
         assert np.isfinite(a).all(), "%s: %s has non-finite values" % (label, k)
         assert err <= tol * scale, "%s: %s max abs err %g > %g (max|ref| %g)" % (label, k, err, tol * scale, scale)
     return rep
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Gradients behind the per-Gaussian chain, beyond the plain bar: a bar that knows each Gaussian's conditioning (round 6)
+# ----------------------------------------------------------------------------------------------------------------------------
+# dL/d(scale, scale_t, rotation, rotation_r) -- and, for splats hundreds of pixels wide, dL/d(cov3D, mean3D, t) -- are cancelling sums
+# of the blend backward's per-Gaussian sums (thousands of fp32 atomics per Gaussian, in whatever order the hardware issues them), which
+# the covariance chain amplifies by two to three orders of magnitude in ANY implementation, the reference included.  What that
+# amplification is for a given Gaussian can be read off the reference itself, deterministically: the oracle evaluates the same backward
+# with its atomics in index order (mode 0), in the opposite order (mode 1), with the per-Gaussian sums accumulated in double (mode 2,
+# "f64": the reference's arithmetic without accumulation error) and with every term of those sums perturbed by what two correct fp32
+# evaluations of it differ by (mode 3, the conditioning probe: 2 ulp of the largest term of the exponent -- 1e-4 of G for a needle
+# hundreds of pixels long -- and 1e-6 of everything else; oracle/fdgs_oracle.c).  nu_g = the largest deviation from f64, relative to
+# its tensor's scale, that any of the three shows on ANY chain element of Gaussian g.
+# The bar for an element of Gaussian g:   |hip - ref| <= 1e-4 * scale   (the plain bar: every well-conditioned Gaussian)
+#                              else   |hip - f64| <= 1e-4 * scale + NOISE_K * scale * nu_g.
+# The oracle side is deterministic; the HIP side is one draw of ITS order noise, NOISE_K is the margin for that (the largest ratio
+# observed over repeated backward runs is printed by the tests; BASELINE.md section 5 records it).  A wrong term in a kernel shows on
+# the thousands of well-conditioned Gaussians (nu_g < 1e-5), where the bar is the plain one.
+CHAIN_ACTIVATED = ("dL_dscale", "dL_dscale_t", "dL_drot", "dL_drot_r")
+CHAIN_ACTIVATED_WIDE = CHAIN_ACTIVATED + ("dL_dcov3D", "dL_dmean3D", "dL_dts")
+NOISE_K = 8.0
+
+
+def gaussian_noise_scale(orders, f64, names):
+    """nu_g (see above): [P] float64.  ``orders``: the reference's gradients in its two accumulation orders (dicts), ``f64``: with
+    double-accumulated sums, ``names``: the chain tensors (per-Gaussian leading dimension)."""
+    nu = None
+    for n in names:
+        x64 = np.asarray(f64[n], np.float64)
+        P = x64.shape[0]
+        scale = max(1.0, float(np.abs(orders[0][n]).max()) if x64.size else 1.0)
+        for o in orders:
+            d = np.abs(np.asarray(o[n], np.float64).reshape(P, -1) - x64.reshape(P, -1)).max(1) / scale
+            nu = d if nu is None else np.maximum(nu, d)
+    return nu
+
+
+def check_backward_noise_aware(hipg, refg, refg_rev, refg_f64, refg_probe, label="", chain=CHAIN_ACTIVATED, tol=GRAD_TOL, K=NOISE_K, scale_like=None):
+    """check_backward with the conditioning-aware bar for the tensors in ``chain`` (every other tensor: the plain bar, no exception).
+    ``scale_like``: {tensor: other tensor} -- a tensor that is a difference of terms of another tensor's magnitude is held to that
+    tensor's scale if larger (dL_dscale_t <- dL_drot, as tests/test_oracle_pin.py and the golden test do).
+    Returns {tensor: (how it passed, max |hip - ref|, scale, elements beyond the plain bar, worst |hip - f64| / bound)}."""
+    chain = tuple(n for n in chain if n in refg)
+    nu = gaussian_noise_scale([refg, refg_rev, refg_probe], refg_f64, chain) if chain else None
+    rep = {}
+    for k, b in refg.items():
+        if k == "dL_dconic":
+            continue
+        a = np.asarray(hipg[k]).reshape(b.shape)
+        assert np.isfinite(a).all(), "%s: %s has non-finite values" % (label, k)
+        scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+        if scale_like and k in scale_like:
+            scale = max(scale, float(np.abs(refg[scale_like[k]]).max()))
+        d = np.abs(a - b)
+        err = float(d.max()) if b.size else 0.0
+        if err <= tol * scale:
+            rep[k] = ("1e-4", err, scale, 0, 0.0)
+            continue
+        assert k in chain, "%s: %s max abs err %g > %g (max|ref| %g) -- not a tensor behind the covariance chain: the plain bar is the bar" % (
+            label, k, err, tol * scale, scale)
+        P = b.shape[0]
+        e = np.abs(a.astype(np.float64) - np.asarray(refg_f64[k], np.float64).reshape(b.shape)).reshape(P, -1).max(1)
+        bound = tol * scale + K * scale * nu
+        ratio = e / bound
+        g = int(np.argmax(ratio))
+        beyond = int((d.reshape(P, -1).max(1) > tol * scale).sum())
+        assert ratio[g] <= 1.0, ("%s: %s of Gaussian %d: |hip - f64| %g > %g = 1e-4 * scale + %g * (what the reference's own accumulation orders and a few-ulp perturbation of its terms do to that Gaussian, %g of scale); "
+                                 "scale %g, %d Gaussians beyond the plain bar, max |hip - ref| %g") % (label, k, g, e[g], bound[g], K, nu[g], scale, beyond, err)
+        rep[k] = ("noise-aware", err, scale, beyond, float(ratio[g]))
+    return rep
+
+
+def fmt_noise_rep(rep):
+    return {k: ("%.2e/%.1e" % (v[1], v[2])) + ("" if v[0] == "1e-4" else " [%d Gaussians beyond 1e-4; worst |hip-f64| at %.2f of its conditioning-aware bound]" % (v[3], v[4]))
+            for k, v in rep.items()}
+
+
+def oracle_four_modes(o, grads):
+    """The oracle's backward in its two accumulation orders, with double-accumulated sums and as the conditioning probe
+    (oracle_set_accumulation 0 / 1 / 2 / 3): four dicts."""
+    args = (grads["grad_color"], grads["grad_depth"], grads["grad_alpha"], grads["grad_flow"])
+    out = []
+    try:
+        for mode in (0, 1, 2, 3):
+            pyoracle.set_accumulation(mode)
+            out.append({k: v.copy() for k, v in o.backward(*args).items()})
+    finally:
+        pyoracle.set_accumulation(0)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Uniformly distributed orientations with a moderate footprint (tests/test_gpu_orientations.py, tests/golden/make_golden.py)
+# ----------------------------------------------------------------------------------------------------------------------------
+
+def splat_anisotropy(ref):
+    """sqrt(lambda_max / lambda_min) of every Gaussian's 2D conic (= of its screen-space covariance incl. the 0.3 low-pass)."""
+    a, b, c = (ref["conic_opacity"][:, i].astype(np.float64) for i in range(3))
+    mid, det = 0.5 * (a + c), a * c - b * b
+    root = np.sqrt(np.maximum(mid * mid - det, 0.0))
+    return np.sqrt((mid + root) / np.maximum(mid - root, 1e-300))
+
+
+def bounded_footprint(scene, limit=40, max_anisotropy=5.0, rounds=10, seed=77, views=None):
+    """Redraws (uniformly) the quaternion pairs of the Gaussians whose splat is wider than ``limit`` pixels or more elongated than
+    1 : ``max_anisotropy`` on screen, until none is left (the last few get the identity): orientations uniform on the sphere
+    CONDITIONED on a moderate footprint.  ``views``: scene-dict overrides (camera tensors, timestamp) of every view the scene is
+    rendered from -- a pair is redrawn if it is out of bounds in any of them.  Returns the fraction redrawn in the first round."""
+    g = torch.Generator().manual_seed(seed)
+    scene["rotations"], scene["rotations_r"] = scene["rotations"].clone(), scene["rotations_r"].clone()
+    first = None
+    for it in range(rounds + 1):
+        bad = None
+        for v in (views or [{}]):
+            ref, _ = run_oracle(dict(scene, **v), None, kind="port")
+            b = (ref["radii"] > limit) | ((ref["radii"] > 0) & (splat_anisotropy(ref) > max_anisotropy))
+            bad = b if bad is None else (bad | b)
+        bad = torch.from_numpy(bad)
+        n = int(bad.sum())
+        first = n if first is None else first
+        if n == 0:
+            break
+        for k in ("rotations", "rotations_r"):
+            if it < rounds:
+                q = torch.randn(n, 4, generator=g)
+                scene[k][bad] = q / q.norm(dim=1, keepdim=True)
+            else:
+                scene[k][bad] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    return first / float(bad.numel())
