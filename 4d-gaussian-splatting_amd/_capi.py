@@ -24,7 +24,7 @@ FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
 _fp = C.c_void_p  # all device pointers travel as void*
 
 
-FDGS_VERSION = 501  # include/fdgs.h; checked against fdgs_version() at import
+FDGS_VERSION = 502  # include/fdgs.h; checked against fdgs_version() at import
 
 
 class _Sized(C.Structure):
@@ -84,7 +84,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_forward_lazy_status", "fdgs_rasterize_backward", "fdgs_preprocess_batch", "fdgs_sh_backward_batch", "fdgs_mark_visible", "fdgs_geometry_bytes",
-            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_sample_every", "fdgs_profile_read",
+            "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_set_sparse_lists_budget", "fdgs_debug_sparse_lists_stats", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_sample_every", "fdgs_profile_read",
             "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
             "fdgs_l1_ssim_num_partials", "fdgs_l1_ssim_value_and_grad", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
@@ -132,6 +132,10 @@ def _load():
     lib.fdgs_debug_run_ahead_stats.restype = None
     lib.fdgs_set_run_ahead.argtypes = [C.c_int32]
     lib.fdgs_set_run_ahead.restype = None
+    lib.fdgs_set_sparse_lists_budget.argtypes = [C.c_int64, C.c_int32]
+    lib.fdgs_set_sparse_lists_budget.restype = C.c_int
+    lib.fdgs_debug_sparse_lists_stats.argtypes = [C.POINTER(C.c_int64)]
+    lib.fdgs_debug_sparse_lists_stats.restype = None
     lib.fdgs_debug_clock_sample.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     lib.fdgs_debug_clock_sample.restype = C.c_int
     lib.fdgs_sh_flush.argtypes = [C.c_int32] * 8 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -283,6 +287,14 @@ def run_ahead_stats():
     """(kept, sorted again, exact) counts of this process's forward calls (fdgs_debug_run_ahead_stats)."""
     a = (C.c_int64 * 3)()
     lib.fdgs_debug_run_ahead_stats(a)
+    return tuple(int(x) for x in a)
+
+
+def sparse_lists_stats():
+    """(forwards with sparse lists, forwards that asked for them and kept compact lists because of the byte budget, bytes of the last
+    run-ahead binning buffer) -- fdgs_debug_sparse_lists_stats."""
+    a = (C.c_int64 * 3)()
+    lib.fdgs_debug_sparse_lists_stats(a)
     return tuple(int(x) for x in a)
 
 

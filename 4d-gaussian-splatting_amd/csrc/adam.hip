@@ -107,7 +107,7 @@ namespace fdgs
 #pragma unroll
 					for (int c = 0; c < 4; c++)
 					{
-						int r = ph + c; if (r >= period) r -= period;
+						int r = ph + c; while (r >= period) r -= period;   // (period may be < 4: segments of the public fdgs_adam_step)
 						adam_update(pe[c], me[c], ve[c], ge[c], r < head ? lr_head : lr, b1, b2, eps, inv_sqrt_bc2);
 					}
 				}

@@ -161,6 +161,8 @@ static int check_scene(const fdgs_scene* s)
 	CHECK_STRUCT(s, fdgs_scene);
 	if (s->P < 0 || s->W <= 0 || s->H <= 0) return fail(FDGS_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", s->P, s->W, s->H);
 	if (div_up(s->W, TILE_X) > 65535 || div_up(s->H, TILE_Y) > 65535) return fail(FDGS_ERR_INVALID_ARG, "image too large for 16-bit tile rectangles");
+	// (the tile order packs a rank into 24 bits, and T = gx * gy is an int everywhere: 2^24 tiles = 4.3 gigapixels)
+	if ((long long)div_up(s->W, TILE_X) * div_up(s->H, TILE_Y) >= (1ll << 24)) return fail(FDGS_ERR_INVALID_ARG, "image too large: %d x %d has 2^24 tiles or more", s->W, s->H);
 	if (s->P == 0) return FDGS_OK;
 	if (!s->means3D || !s->opacities || !s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
 		return fail(FDGS_ERR_INVALID_ARG, "means3D / opacities / bg / viewmatrix / projmatrix / campos must not be NULL");
@@ -205,6 +207,21 @@ static std::atomic<bool> g_run_ahead_enabled{[]() { const char* e = getenv("FDGS
 constexpr int FDGS_MAX_DEVICES = 64;   // = the size of g_box_of
 constexpr int FDGS_GUESS_SLOTS = 8;    // = the size of g_guesses
 extern "C" void fdgs_set_run_ahead(int32_t enable) { g_run_ahead_enabled.store(enable != 0); }
+// Byte budget of fdgs_forward_out.sparse_lists (include/fdgs.h): a forward takes the sparse layout only when its binning buffer --
+// T * cap entries -- stays within max(g_sparse_min_bytes, g_sparse_factor x the compact buffer the same guess would get).
+static std::atomic<long long> g_sparse_min_bytes{[]() { const char* e = getenv("FDGS_SPARSE_BUDGET_MB"); return (e && atoll(e) > 0 ? atoll(e) : 1024ll) << 20; }()};
+static std::atomic<int> g_sparse_factor{4};
+static std::atomic<long long> g_sparse_stats[3];   // forwards with sparse lists, forwards that asked for them and got compact lists (budget), bytes of the last binning buffer
+extern "C" int fdgs_set_sparse_lists_budget(int64_t min_bytes, int32_t factor)
+{
+	if (min_bytes < 0 || factor < 1) return FDGS_ERR_INVALID_ARG;
+	g_sparse_min_bytes.store(min_bytes); g_sparse_factor.store(factor);
+	return FDGS_OK;
+}
+extern "C" void fdgs_debug_sparse_lists_stats(int64_t* counts3)
+{
+	for (int k = 0; k < 3; k++) counts3[k] = (int64_t)g_sparse_stats[k].load();
+}
 extern "C" void fdgs_debug_run_ahead_stats(int64_t* counts3)
 {
 	for (int k = 0; k < 3; k++) counts3[k] = (int64_t)g_run_ahead[k].load();
@@ -478,7 +495,18 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		long long q = 64;
 		while (q * 16 <= ahead_longest) q <<= 1;
 		const long long cap_tile = ((long long)ahead_longest + q - 1) / q * q;
-		if (cap_tile * (long long)T <= 0x7fffffffLL) sparse_cap = (uint32_t)cap_tile;
+		// The price is address space, and it has a budget: ONE long list (a real capture has hot tiles: 16 k entries in one tile of a
+		// 2704 x 2028 image would make T * cap = 4.2 GB per forward in flight) must not turn a 200 MB buffer into gigabytes.  Beyond
+		// max(1 GiB, 4 x the compact buffer of the same guess) -- fdgs_set_sparse_lists_budget -- the forward keeps compact lists.
+		if (cap_tile * (long long)T <= 0x7fffffffLL)
+		{
+			const size_t sparse_bytes = bin_layout((int)(cap_tile * T), (int)cap_tile > lds_cap, T).total;
+			const size_t compact_bytes = bin_layout((int)ahead_cap, ahead_longest > lds_cap, T).total;
+			const long long budget = std::max<long long>(g_sparse_min_bytes.load(std::memory_order_relaxed),
+			                                             (long long)g_sparse_factor.load(std::memory_order_relaxed) * (long long)compact_bytes);
+			if ((long long)sparse_bytes <= budget) sparse_cap = (uint32_t)cap_tile;
+		}
+		g_sparse_stats[sparse_cap != 0u ? 0 : 1]++;
 	}
 	if (sparse_cap == 0u)
 	{
@@ -495,6 +523,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		BL = bin_layout((int)total, has_scratch, T);
 		bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
 		if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+		g_sparse_stats[2].store((long long)BL.total);
 		uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
 		uint32_t* pairs = (uint32_t*)(bin + BL.pairs);
 		STAGE(FDGS_STAGE_TILE_SCATTER, launch_tile_scatter(rect, depths, P, gx, T, counters, pairs, ctl, (uint32_t)total, nullptr, stream, sparse_cap), "tile scatter (sparse)");
@@ -527,6 +556,7 @@ extern "C" int fdgs_rasterize_forward(const fdgs_scene* scene, const fdgs_forwar
 		BL = bin_layout((int)ahead_cap, has_scratch, T);
 		bin = (char*)alloc(alloc_user, FDGS_BUF_BINNING, BL.total);
 		if (!bin) return fail(FDGS_ERR_ALLOC, "scratch allocator returned NULL (binning)");
+		g_sparse_stats[2].store((long long)BL.total);
 		if ((rc = enqueue_rest(ahead_cap, ahead_longest, true)) != FDGS_OK) return rc;
 	}
 

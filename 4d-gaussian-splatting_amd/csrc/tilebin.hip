@@ -809,7 +809,7 @@ namespace fdgs
 		const int c4 = min(1024 * TS_ITEMS, lds_cap), c5 = min(1024 * TS_ITEMS_LONG, lds_cap);
 		const auto lds_keys = [&](int c) { return min(c, max(64, div_up(longest_lds, 64) * 64)); };
 		const bool overflow = max_count > lds_cap;   // somebody has to take the global path
-		if (div_up(T, NUM_XCDS_BIN) >= (1 << 24)) { tile_order = nullptr; order_out = nullptr; }   // no order is written (launch_tile_bin)
+		if (T >= (1 << 24)) { tile_order = nullptr; order_out = nullptr; }   // no order is written (launch_tile_bin; check_scene rejects such images anyway)
 		if (sparse_cap) tile_order = nullptr;   // the order is only being written by this launch: tiles by index
 		const uint32_t sc = sparse_cap;
 		hipError_t e = hipSuccess;

@@ -152,6 +152,12 @@ class StepPipeline:
         carried = self.overlap_steps and self._carry is not None and self._carry == self._model_token()
         self._carry = None
         _LAST_STEPPER[id(m)] = weakref.ref(self)
+        # A carried step is only in order when its FIRST forward is a split_colour forward whose colour launch goes onto stream A, behind
+        # the previous step's SH update.  The view-batched colour pass (batch_views, B > 1) and the batched step (sh_group > 1) evaluate SH
+        # colours on stream F: they must not start before that update is through (nondeterministic colours otherwise, with no error)
+        if carried and ((self.batch_views and B > 1) or (self.sh_group > 1 and B > 1)):
+            self.sF.wait_stream(self.sA)
+            carried = False
         if carried:
             self.steps_carried += 1
         else:

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 501 /* 0.5.1 (round 5: fdgs_forward_out.sparse_lists, .colour_stream).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+#define FDGS_VERSION 502 /* 0.5.2 (round 6: fdgs_set_sparse_lists_budget; round 5: fdgs_forward_out.sparse_lists, .colour_stream).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
                             (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
                             FDGS_VERSION: a binding built against another revision of this header is turned away instead of
                             having the library read past the end of a shorter struct. */
@@ -169,7 +169,10 @@ typedef struct fdgs_forward_out
 	                         The lists themselves -- which instances, in which order -- are what they are without the flag; `ranges` holds
 	                         (t * cap, t * cap + n_t) instead of the reference's prefix sums (identifyTileRanges), num_rendered (reported
 	                         lazily) is the same sum.  A list that outgrows cap is cut and the forward reported as failed, like any lazy
-	                         forward that does not fit.  Costs address space: T * cap entries of 12 bytes instead of num_rendered. */
+	                         forward that does not fit.  Costs address space: T * cap entries of 12.5 bytes instead of num_rendered --
+	                         within a BUDGET: when T * cap entries would take more than max(1 GiB, 4 x the compact buffer the same guess
+	                         gets) the forward keeps compact lists (count + scan launches, prefix-sum `ranges`), so one hot tile of a real
+	                         capture cannot turn a 200 MB buffer into gigabytes (fdgs_set_sparse_lists_budget). */
 	void* colour_stream;  /* with split_colour = 1: NULL = the library's own second stream; otherwise the hipStream_t the SH -> RGB
 	                         launch goes onto (after an event of the geometry launch; the caller's stream waits for its event before the
 	                         blend).  Everything already enqueued on that stream comes first -- so a caller whose optimizer updates the
@@ -262,6 +265,15 @@ int fdgs_forward_lazy_status(int32_t wait, void* stream, int32_t* pending, int32
  * calling thread's previous call; 0: it always waits and asks the allocator for exactly fdgs_binning_bytes(num_rendered)
  * (+ the long-list scratch), as the reference does.  Process-wide. */
 void fdgs_set_run_ahead(int32_t enable);
+
+/* Budget of fdgs_forward_out.sparse_lists: a forward takes the sparse layout only while its binning buffer stays within
+ * max(min_bytes, factor x the bytes of the compact buffer sized from the same run-ahead guess).  Defaults: 1 GiB (environment:
+ * FDGS_SPARSE_BUDGET_MB), 4.  min_bytes = 0, factor = 1: never more than the compact buffer, i.e. practically always compact.
+ * Process-wide.  Returns FDGS_ERR_INVALID_ARG for min_bytes < 0 or factor < 1. */
+int fdgs_set_sparse_lists_budget(int64_t min_bytes, int32_t factor);
+/* Introspection: counts3[0] forwards that ran with sparse lists, [1] forwards that asked for them and kept compact lists because of the
+ * budget, [2] bytes of the binning buffer the last run-ahead forward asked its allocator for. */
+void fdgs_debug_sparse_lists_stats(int64_t* counts3);
 
 /* View-batched preprocess (the views of ONE optimizer step: same Gaussian tensors, same P / M / degrees / flags; cameras and
  * timestamps differ).  The 12 M bytes of SH coefficients per Gaussian are most of what the preprocess reads, and they are

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_capi.lib, n), "libfdgs.so does not export %s" % n
         assert n in _capi.EXPORTED or n in ("fdgs_alloc_fn",), "binding list misses %s" % n
-    assert _capi.lib.fdgs_version() == _capi.FDGS_VERSION == 501
+    assert _capi.lib.fdgs_version() == _capi.FDGS_VERSION == 502
     with open(os.path.join(ROOT, "include", "fdgs.h")) as f:
         assert re.search(r"#define FDGS_VERSION (\d+)", f.read()).group(1) == str(_capi.FDGS_VERSION)
 

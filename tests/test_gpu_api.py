@@ -628,6 +628,56 @@ def test_step_pipeline_overlap_steps_equals_plain(gpu_device):
         assert merr <= 10.0 * max((runs["plain again"][3] - runs["plain"][3]).abs().max().item(), 1e-7), merr
 
 
+@pytest.mark.parametrize("variant", ["batch_views", "sh_group"])
+def test_step_pipeline_overlap_steps_with_view_batching_waits_for_the_sh_update(variant, gpu_device):
+    """overlap_steps leaves step k's SH update running on stream A; a step whose first SH colours are NOT a split_colour launch on that
+    stream -- the view-batched colour pass (batch_views) or the batched step (sh_group > 1) on stream F -- must wait for it (round-5
+    advisor finding: it did not, and read coefficients the update was still writing).  Steps with 1 view (carried, split colour) and
+    3 views (batched) alternate, against the same sequence without overlap_steps.  The race is made certain instead of likely: a
+    10 ms sleep kernel is put in front of every SH update (on its stream), so a colour pass that does not wait for stream A
+    reads the coefficients of BEFORE the update (lr 0.02 per step: its loss is off by ~1e-3 relative; two runs of the plain pipeline
+    differ by 1e-5)."""
+    from fdgs import train_host
+    from fdgs.pipeline import StepPipeline
+    cfg = synth.SceneConfig("ovb", 60012, 256, 192, 3, 2, 0.012, 10.0, True, 4, False)
+    scene = synth.make_scene(cfg, seed=6, pose="rig1")
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    pipe = train_host.PipelineFlags()
+    B, steps = 3, 6
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / B * scene["time_duration"]) for b in range(B)]
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    gts = [torch.rand(3, scene["H"], scene["W"], generator=gen).to(gpu_device) for _ in range(B)]
+    kw = dict(batch_views=True) if variant == "batch_views" else dict(sh_group=3, lazy=False)
+    runs = {}
+    for mode in ("plain", "overlap", "plain again"):
+        m = train_host.GaussianParams(scene, gpu_device)
+        opt = train_host.make_optimizer(m)
+        opt.set_lr("_features", 0.02, 0.02)
+        sp = StepPipeline(m, opt, world_size=1, lambda_dssim=0.2, overlap_steps=mode == "overlap", **kw)
+        update = opt.step_sh_staged
+
+        def slow_update(*a, _update=update, **k):      # ~10 ms in front of every SH update, on the stream the pipeline puts it on
+            torch.cuda._sleep(20_000_000)
+            return _update(*a, **k)
+        opt.step_sh_staged = slow_update
+        losses = []
+        for k in range(steps):
+            n = 1 if k % 2 == 0 else B
+            _res, ls = sp.step(cams[:n], gts[:n], pipe, bg)
+            losses += [l.clone() for l in ls]      # (no float() here: reading a loss would make the HOST wait for the SH update, as bench.py does not)
+        torch.cuda.synchronize()
+        runs[mode] = (m.flat.detach().clone(), [float(l) for l in losses], sp.steps_carried)
+    np.testing.assert_allclose(runs["plain again"][1], runs["plain"][1], rtol=1e-4, atol=1e-6)     # (what two runs of one pipeline differ by)
+    np.testing.assert_allclose(runs["overlap"][1], runs["plain"][1], rtol=1e-4, atol=1e-6)
+    b, e = m.offsets["_features"]
+    perr = (runs["overlap"][0][b:e] - runs["plain"][0][b:e]).abs()
+    noise = (runs["plain again"][0][b:e] - runs["plain"][0][b:e]).abs()
+    assert (perr > 1e-2).float().mean().item() <= max(1e-3, 4.0 * (noise > 1e-2).float().mean().item()), (perr > 1e-2).float().mean().item()
+    # batch_views: the 1-view steps 2 and 4 are carried (they start under the previous step's SH update); the batched steps 1, 3, 5 must
+    # not be.  sh_group: the batched step puts its SH update on stream F, so nothing is left to carry into the 1-view steps either
+    assert runs["plain"][2] == 0 and runs["overlap"][2] == (2 if variant == "batch_views" else 0), (runs["plain"][2], runs["overlap"][2])
+
+
 def test_backward_without_the_per_view_outputs(gpu_device):
     """fdgs_backward_out.dL_dcolors / dL_dcov3D / dL_dflows = NULL (``per_view_outputs=False``, what StepPipeline passes): the three
     slots come back as None, everything else -- dL_dmeans2D and every parameter gradient -- is what the full call writes (the two

@@ -130,7 +130,7 @@ def test_adam_segment_kernel_equals_general_kernel(gpu_device):
     """fdgs_adam_step takes the per-segment kernel (one segment per blockIdx.y: the learning rate is a workgroup constant) when the
     segment table tiles [0, n), and the general kernel (per-element search) otherwise.  Same arithmetic: bit-identical parameters and
     moments -- with segment boundaries that are not multiples of 4, a segment shorter than a float4, a periodic head (the SH DC
-    rate), a segment that starts before the chunk (negative begin: step_range) and one that ends behind it."""
+    rate; also periods of 1, 2 and 3 elements, shorter than a float4), a segment that starts before the chunk (negative begin: step_range) and one that ends behind it."""
     import ctypes as C
     from fdgs import _capi
     n = 4 * 2503 + 3
@@ -140,12 +140,13 @@ def test_adam_segment_kernel_equals_general_kernel(gpu_device):
     bounds = [-77, 3, 5, 1000, 1001, 4099, 7001, n + 50]     # segments [b_i, b_i+1): clipped to [0, n) they tile it
     segs = []
     for i, (b, e) in enumerate(zip(bounds[:-1], bounds[1:])):
-        period, head = (21, 3) if i in (3, 5) else (0, 0)
+        # (periods below 4: a float4 spans more than one period -- round-5 advisor finding: the phase was reduced once only)
+        period, head = {3: (21, 3), 5: (21, 3), 1: (2, 1), 4: (1, 1), 2: (3, 2), 6: (2, 1)}.get(i, (0, 0))
         segs.append(_capi.FdgsAdamSegment(b, e, 1e-3 * (i + 1), 5e-2 * (i + 1), period, head))
     tiling = (_capi.FdgsAdamSegment * len(segs))(*segs)
     # the same table with the last segment cut one element short of n: does not tile -> general kernel; element n - 1 gets lr = 0
     segs2 = list(segs)
-    segs2[-1] = _capi.FdgsAdamSegment(bounds[-2], n - 1, segs[-1].lr, segs[-1].lr_head, 0, 0)
+    segs2[-1] = _capi.FdgsAdamSegment(bounds[-2], n - 1, segs[-1].lr, segs[-1].lr_head, segs[-1].period, segs[-1].head)
     general = (_capi.FdgsAdamSegment * len(segs2))(*segs2)
 
     def run(table):

@@ -152,3 +152,80 @@ def test_sparse_list_overflow_is_reported(gpu_device):
     _pend, failed, reported = _capi.forward_lazy_status(gpu_device, wait=True)
     assert again[0] == -1 and failed == 0 and reported == [want[0]]
     assert torch.equal(again[1], want[1]) and torch.equal(again[5], want[5])
+
+
+def test_sparse_lists_budget_falls_back_to_compact_lists(gpu_device):
+    """fdgs_set_sparse_lists_budget: T * cap entries of address space are only spent while they stay within max(min_bytes, factor x the
+    compact buffer).  With the budget taken away a lazy forward that asks for sparse lists keeps COMPACT lists (prefix-sum ranges, count
+    + scan launches) and everything it returns is what the sparse forward returns; the counters say which layout ran."""
+    from fdgs import _capi
+    cfg = SC("spb", 16033, 320, 240, 1, 0, 0.03, 1.0, True, 4, True)
+    scene = synth.make_scene(cfg, seed=9, pose="rig2")
+    sc = scene_to_device(scene, gpu_device)
+    _capi.forward_lazy_status(gpu_device, wait=True)
+    first = _fwd(sc)
+    want_lists, want_rg, want_nc, _ = _lists(first, cfg.P, cfg.W, cfg.H)
+    assert _capi.lib.fdgs_set_sparse_lists_budget(-1, 4) != 0 and _capi.lib.fdgs_set_sparse_lists_budget(0, 0) != 0
+    try:
+        s0 = _capi.sparse_lists_stats()
+        sparse = _fwd(sc, lazy=True, sparse_lists=True)
+        s1 = _capi.sparse_lists_stats()
+        assert (s1[0] - s0[0], s1[1] - s0[1]) == (1, 0)
+        assert _capi.lib.fdgs_set_sparse_lists_budget(0, 1) == 0          # never more than the compact buffer
+        compact = _fwd(sc, lazy=True, sparse_lists=True)
+        s2 = _capi.sparse_lists_stats()
+        assert (s2[0] - s1[0], s2[1] - s1[1]) == (0, 1) and s2[2] < s1[2]
+    finally:
+        assert _capi.lib.fdgs_set_sparse_lists_budget(1 << 30, 4) == 0
+    pend, failed, reported = _capi.forward_lazy_status(gpu_device, wait=True)
+    assert (pend, failed, reported) == (0, 0, [first[0], first[0]])
+    got_lists, got_rg, got_nc, _ = _lists(compact, cfg.P, cfg.W, cfg.H)
+    np.testing.assert_array_equal(got_rg, want_rg)                        # compact: the reference's prefix sums
+    for t in range(len(want_lists)):
+        assert np.array_equal(got_lists[t], want_lists[t])
+    sp_rg = _lists(sparse, cfg.P, cfg.W, cfg.H)[1]
+    assert not np.array_equal(sp_rg, want_rg)                             # (the sparse forward really had another layout)
+    for i in (1, 2, 3, 4, 5):
+        assert torch.equal(compact[i], first[i]) and torch.equal(sparse[i], first[i])
+
+
+def test_one_hot_tile_does_not_buy_gigabytes(gpu_device):
+    """A real capture has hot tiles.  2704 x 2028 (T = 21 717 tiles) with 17 000 Gaussians projecting into ONE tile: sparse lists would
+    take T x cap(~25 k) = 550 M slots = 6.9 GB per forward in flight for 0.2 M instances; the default budget (max(1 GiB, 4 x compact))
+    sends that forward through the compact layout: same image bit for bit, a binning buffer of a few MB."""
+    from fdgs import _capi
+    cfg = SC("hot", 60037, 2704, 2028, 0, 0, 0.004, 1.0, True, 4, True)
+    scene = synth.make_scene(cfg, seed=10)
+    n_hot = 17000
+    g = torch.Generator().manual_seed(3)
+    hot = scene["means3D"][:n_hot]
+    # a spot a few pixels wide at depth 4 around a tile centre: pixel (1352 +- 256, 1014 +- 206) with focal 0.9 W
+    focal = 0.9 * cfg.W
+    hot[:, 0:2] = torch.tensor([256.0, -206.0]) * 4.0 / focal + 0.0012 * torch.randn(n_hot, 2, generator=g)
+    hot[:, 2] = 0.0
+    scene["scales"][:n_hot] = 0.0008
+    scene["ts"][:n_hot] = scene["timestamp"]
+    sc = scene_to_device(scene, gpu_device)
+    _capi.forward_lazy_status(gpu_device, wait=True)
+    first = _fwd(sc)
+    lists, rg, _nc, _ = _lists(first, cfg.P, cfg.W, cfg.H)
+    longest = int((rg[:, 1] - rg[:, 0]).max())
+    assert longest > 12000 and first[0] < 600000, (longest, first[0])
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(gpu_device)
+    base = torch.cuda.memory_allocated(gpu_device)
+    s0 = _capi.sparse_lists_stats()
+    res = _fwd(sc, lazy=True, sparse_lists=True)
+    pend, failed, reported = _capi.forward_lazy_status(gpu_device, wait=True)
+    s1 = _capi.sparse_lists_stats()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated(gpu_device) - base
+    assert res[0] == -1 and (pend, failed, reported) == (0, 0, [first[0]])
+    assert (s1[0] - s0[0], s1[1] - s0[1]) == (0, 1), "the hot tile went through the sparse layout"
+    T = ((cfg.W + 15) // 16) * ((cfg.H + 15) // 16)
+    would_be = T * (longest + longest // 2) * 12.5
+    print("hot tile: longest list %d of R %d; binning buffer %.1f MB (sparse lists would take %.1f GB); peak allocation of the forward %.1f MB" % (
+        longest, first[0], s1[2] / 2**20, would_be / 2**30, peak / 2**20))
+    assert s1[2] < 64 << 20 and res[7].numel() == s1[2] and peak < 512 << 20 and would_be > 4 * 2**30
+    for i in (1, 3, 4, 5):
+        assert torch.equal(res[i], first[i])
