@@ -109,6 +109,7 @@ namespace fdgs
 	__device__ __forceinline__ float3 sh_weighted(const float* l, const float* __restrict__ sh, int lo, int hi, int off)
 	{
 		float3 acc = scl3(l[lo - off], ld3(sh, lo));
+#pragma unroll
 		for (int k = lo + 1; k <= hi; k++) acc = add3(acc, scl3(l[k - off], ld3(sh, k)));
 		return acc;
 	}
@@ -214,23 +215,19 @@ namespace fdgs
 		return make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
 	}
 
-	// PART 0: everything.  The forward can also run it in two launches (fdgs_forward_out.split_colour): PART 1 = the geometry
-	// (everything the tile binning needs; colour left at zero), PART 2 = the SH colour of the Gaussians PART 1 kept (radius > 0),
-	// on a second stream next to the binning -- same arithmetic, same results.
-	template <int PART>
-	__global__ void __launch_bounds__(256) preprocess_fwd_kernel(const PreArgs a)
+	// The geometry of one Gaussian (everything of preprocessCUDA but the colour): forward.cu:279-352 / 242-276 / 431-437, the near cull,
+	// the EWA projection, conic, radius and tile rectangle.  ``in``: the inputs AS STORED (raw parameters when a.raw: the activations run
+	// here); shared by the one-launch kernel, the geometry half of the split forward and the streaming kernel below.
+	struct GeoIn { float3 p; float opacity; float3 sc; float sct; float4 q, qr; float t; };
+	struct GeoOut
 	{
-		// every lane stays until the end: the SH blocks are staged cooperatively per wave
-		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
-		// first kernel of the forward: clears the tile counters of the binning passes (more cells than Gaussians: stride)
-		if (PART != 2)
-			for (int c = tid_g; c < a.bin_counter_words; c += gridDim.x * blockDim.x) a.bin_counters[c] = 0u;
-		const bool valid = tid_g < a.P;
-		const int idx = valid ? tid_g : a.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
-
-		float3 p_orig = ld3(a.means3D, idx);
-		const float3 p_in = p_orig;
-		float opacity = a.opacities[idx];
+		bool alive; int radius; uint32_t tiles; ushort4 rect; float depth; float2 pix; float3 conic; float opacity; float3 p_orig; float cov[6];
+	};
+	__device__ __forceinline__ void pre_geometry(const PreArgs& a, const GeoIn& in, const float* __restrict__ cov_precomp, const bool valid, GeoOut& o,
+	                                             const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix)
+	{
+		float3 p_orig = in.p;
+		float opacity = in.opacity;
 		if (a.raw) opacity = act_sigmoid(opacity);
 		float cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 		bool alive = valid;
@@ -240,22 +237,17 @@ namespace fdgs
 		float depth = 0.0f;
 		float2 pix = make_float2(0.f, 0.f);
 		float3 conic = make_float3(0.f, 0.f, 0.f);
-		float3 rgb = make_float3(0.f, 0.f, 0.f);
-		uint8_t clampbits = 0;
-
-		if constexpr (PART == 2) alive = valid && a.radii[idx] > 0;   // what the geometry launch kept
-		else {
-		if (a.cov3D_precomp != nullptr)
+		if (cov_precomp != nullptr)
 		{
 #pragma unroll
-			for (int k = 0; k < 6; k++) cov[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+			for (int k = 0; k < 6; k++) cov[k] = cov_precomp[k];
 		}
 		else if (a.rot_4d)
 		{
 			// forward.cu:279-352
-			float3 sc = ld3(a.scales, idx);
-			float sct = a.scales_t[idx];
-			float4 q = reinterpret_cast<const float4*>(a.rotations)[idx], qr = reinterpret_cast<const float4*>(a.rotations_r)[idx];
+			float3 sc = in.sc;
+			float sct = in.sct;
+			float4 q = in.q, qr = in.qr;
 			if (a.raw)
 			{
 				float unused;
@@ -265,7 +257,7 @@ namespace fdgs
 				qr = act_normalize(qr, &unused);
 			}
 			const float mod = a.scale_modifier;
-			const float dt = a.timestamp - a.ts[idx];
+			const float dt = a.timestamp - in.t;
 			const M4 S = diag4(mod * sc.x, mod * sc.y, mod * sc.z, mod * sct);
 			M4 Ml, Mr;
 			build_Ml_Mr(q, qr, Ml, Mr);
@@ -292,8 +284,8 @@ namespace fdgs
 		else
 		{
 			// forward.cu:242-276
-			float3 sc = ld3(a.scales, idx);
-			float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+			float3 sc = in.sc;
+			float4 q = in.q;
 			if (a.raw)
 			{
 				float unused;
@@ -314,8 +306,8 @@ namespace fdgs
 			if (a.gaussian_dim == 4)
 			{
 				// forward.cu:431-437 (scales_t used as a variance)
-				const float dt = a.ts[idx] - a.timestamp;
-				const float sigma = (a.raw ? expf(a.scales_t[idx]) : a.scales_t[idx]) * mod;
+				const float dt = in.t - a.timestamp;
+				const float sigma = (a.raw ? expf(in.sct) : in.sct) * mod;
 				const float marginal_t = expf((float)(-0.5 * dt * dt / ((a.prefilter_var > 0.0) ? (a.prefilter_var + sigma) : sigma)));
 				if (marginal_t <= 0.05) alive = false;
 				else opacity *= marginal_t;
@@ -324,14 +316,14 @@ namespace fdgs
 
 		if (alive)
 		{
-			const float3 p_view = xform4x3(p_orig, a.viewmatrix);
+			const float3 p_view = xform4x3(p_orig, viewmatrix);
 			alive = !(p_view.z <= 0.2f); // auxiliary.h:153
 			if (alive)
 			{
-				const float4 p_hom = xform4x4(p_orig, a.projmatrix);
+				const float4 p_hom = xform4x4(p_orig, projmatrix);
 				const float p_w = 1.0f / (p_hom.w + 0.0000001f);
 				const float p_proj_x = p_hom.x * p_w, p_proj_y = p_hom.y * p_w;
-				const Cov2D c2 = project_cov(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov, a.viewmatrix);
+				const Cov2D c2 = project_cov(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov, viewmatrix);
 				const float cx = c2.a + 0.3f, cy = c2.b, cz = c2.c + 0.3f;
 				const float det = (cx * cz - cy * cy);
 				if (det == 0.0f) alive = false;
@@ -365,7 +357,71 @@ namespace fdgs
 			}
 		}
 
-		}   // PART != 2
+		o.alive = alive; o.radius = radius; o.tiles = tiles; o.rect = rect; o.depth = depth; o.pix = pix; o.conic = conic;
+		o.opacity = opacity; o.p_orig = p_orig;
+#pragma unroll
+		for (int k = 0; k < 6; k++) o.cov[k] = cov[k];
+	}
+
+	// PART 0: everything.  The forward can also run it in two launches (fdgs_forward_out.split_colour): PART 1 = the geometry
+	// (everything the tile binning needs; colour left at zero), PART 2 = the SH colour of the Gaussians PART 1 kept (radius > 0),
+	// on a second stream next to the binning -- same arithmetic, same results.
+#ifdef FDGS_PRE_WAVES   // A/B: hold the kernel to 512 / FDGS_PRE_WAVES registers (3: 168 VGPRs and 66 spills; default: 235 VGPRs, two waves per SIMD)
+#define FDGS_PRE_OCC __attribute__((amdgpu_waves_per_eu(FDGS_PRE_WAVES, FDGS_PRE_WAVES)))
+#else
+#define FDGS_PRE_OCC
+#endif
+	template <int PART>
+	__global__ void __launch_bounds__(256) FDGS_PRE_OCC preprocess_fwd_kernel(const PreArgs a)
+	{
+		// every lane stays until the end: the SH blocks are staged cooperatively per wave
+		const int tid_g = blockIdx.x * blockDim.x + threadIdx.x;
+		// first kernel of the forward: clears the tile counters of the binning passes (more cells than Gaussians: stride)
+		if (PART != 2)
+			for (int c = tid_g; c < a.bin_counter_words; c += gridDim.x * blockDim.x) a.bin_counters[c] = 0u;
+		const bool valid = tid_g < a.P;
+		const int idx = valid ? tid_g : a.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
+
+		float3 p_orig = ld3(a.means3D, idx);
+		const float3 p_in = p_orig;
+		float opacity = a.opacities[idx];   // (as stored: pre_geometry applies the activation of a raw parameter)
+		float cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+		bool alive = valid;
+		int radius = 0;
+		uint32_t tiles = 0;
+		ushort4 rect = make_ushort4(0, 0, 0, 0);
+		float depth = 0.0f;
+		float2 pix = make_float2(0.f, 0.f);
+		float3 conic = make_float3(0.f, 0.f, 0.f);
+		float3 rgb = make_float3(0.f, 0.f, 0.f);
+		uint8_t clampbits = 0;
+
+		if constexpr (PART == 2) alive = valid && a.radii[idx] > 0;   // what the geometry launch kept
+		else
+		{
+			GeoIn in;
+			in.p = p_orig; in.opacity = opacity;
+			in.sc = make_float3(0.f, 0.f, 0.f); in.sct = 0.f; in.t = 0.f;
+			in.q = make_float4(1.f, 0.f, 0.f, 0.f); in.qr = in.q;
+			if (a.cov3D_precomp == nullptr)
+			{
+				in.sc = ld3(a.scales, idx);
+				in.q = reinterpret_cast<const float4*>(a.rotations)[idx];
+				if (a.rot_4d)
+				{
+					in.sct = a.scales_t[idx];
+					in.qr = reinterpret_cast<const float4*>(a.rotations_r)[idx];
+					in.t = a.ts[idx];
+				}
+				else if (a.gaussian_dim == 4) { in.t = a.ts[idx]; in.sct = a.scales_t[idx]; }
+			}
+			GeoOut o;
+			pre_geometry(a, in, a.cov3D_precomp != nullptr ? a.cov3D_precomp + 6 * (size_t)idx : nullptr, valid, o, a.viewmatrix, a.projmatrix);
+			alive = o.alive; radius = o.radius; tiles = o.tiles; rect = o.rect; depth = o.depth; pix = o.pix; conic = o.conic;
+			opacity = o.opacity; p_orig = o.p_orig;
+#pragma unroll
+			for (int k = 0; k < 6; k++) cov[k] = o.cov[k];
+		}
 
 		if (a.colors_precomp != nullptr)
 		{
@@ -450,6 +506,7 @@ namespace fdgs
 		a.records[3 * (size_t)idx + 1] = make_float4(conic.z, radius > 0 ? opacity : 0.0f, rgb.x, rgb.y);
 		a.records[3 * (size_t)idx + 2] = make_float4(rgb.z, depth, flow.x, flow.y);
 	}
+
 
 	// part: 0 = one launch; 1 / 2 = the geometry / colour halves (see the kernel)
 	hipError_t launch_preprocess_fwd(const fdgs_scene& s, const fdgs_forward_out& out, char* geom, uint32_t* bin_counters, int part,

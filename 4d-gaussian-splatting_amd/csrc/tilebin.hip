@@ -98,7 +98,7 @@ namespace fdgs
 	// or, with sparse lists, of the sort launch.
 	// counts: [T] list lengths (left alone: a scatter pass that is launched a second time orders again); tmp: [T] scratch; order: [T];
 	// s_cls: ORDER_BUCKETS words of LDS.  T < 2^24 (the launchers check).
-	constexpr int NUM_XCDS_BIN = 8;     // blend_common.h NUM_XCDS
+	[[maybe_unused]] constexpr int NUM_XCDS_BIN = 8;     // blend_common.h NUM_XCDS
 	constexpr int ORDER_BUCKETS = 64;   // = WAVE: one wave scans the classes
 	__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tmp, int T, uint32_t gmax,
 	                                                 uint32_t* __restrict__ order, uint32_t* s_cls)

@@ -749,3 +749,4 @@ def test_mailbox_ring_wraps_correctly_in_a_fresh_thread(gpu_device):
     assert "error" not in out, out.get("error")
     assert out["rs"] == [want[0]] * 70, out["rs"]
     assert out["lazy_r"] == [want[0]] * 70 and out["failed"] == 0 and out["bad"] == 0, (out["lazy_r"], out["bad"])
+
