@@ -85,7 +85,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 # every symbol include/fdgs.h declares
 EXPORTED = ("fdgs_rasterize_forward", "fdgs_forward_lazy_status", "fdgs_rasterize_backward", "fdgs_preprocess_batch", "fdgs_sh_backward_batch", "fdgs_mark_visible", "fdgs_geometry_bytes",
             "fdgs_image_bytes", "fdgs_binning_bytes", "fdgs_debug_views", "fdgs_debug_activations", "fdgs_debug_tile_sort_limits", "fdgs_debug_block_reaches", "fdgs_debug_run_ahead_stats", "fdgs_set_run_ahead", "fdgs_set_sparse_lists_budget", "fdgs_debug_sparse_lists_stats", "fdgs_debug_clock_sample", "fdgs_sh_flush", "fdgs_profile_enable", "fdgs_profile_sample_every", "fdgs_profile_read",
-            "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss",
+            "fdgs_profile_reset", "fdgs_stage_name", "fdgs_l1_ssim_forward", "fdgs_l1_ssim_backward", "fdgs_l1_ssim_loss", "fdgs_l1_ssim_loss_batch",
             "fdgs_l1_ssim_num_partials", "fdgs_l1_ssim_value_and_grad", "fdgs_adam_step", "fdgs_adam_step_sh", "fdgs_densify_classify", "fdgs_densify_gather", "fdgs_densify_split", "fdgs_densify_stats_local", "fdgs_densify_stats_apply", "fdgs_knn_scratch_bytes", "fdgs_dist2_knn3", "fdgs_last_error", "fdgs_version")
 NUM_STAGES = 11
 
@@ -157,6 +157,8 @@ def _load():
     lib.fdgs_l1_ssim_backward.restype = C.c_int
     lib.fdgs_l1_ssim_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
     lib.fdgs_l1_ssim_loss.restype = C.c_int
+    lib.fdgs_l1_ssim_loss_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    lib.fdgs_l1_ssim_loss_batch.restype = C.c_int
     lib.fdgs_l1_ssim_value_and_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p]
     lib.fdgs_l1_ssim_value_and_grad.restype = C.c_int

@@ -685,9 +685,12 @@ extern "C" int fdgs_l1_ssim_backward(const float* img, const float* gt, int32_t 
 namespace fdgs
 {
 	// loss = (1 - lambda) * sum(l1) / n + lambda * (1 - sum(ssim) / n), fixed summation order (deterministic)
+	// (blockIdx.x = view: the batch call below reduces every view of an optimizer step in ONE launch; view_stride = floats between the
+	// partial arrays of consecutive views, 0 for the single call)
 	__global__ void __launch_bounds__(1024) l1_ssim_finish_kernel(const float* __restrict__ partial_l1, const float* __restrict__ partial_ssim,
-	                                                              int nparts, float inv_n, float lambda_dssim, float* __restrict__ out)
+	                                                              int nparts, float inv_n, float lambda_dssim, float* __restrict__ out, long long view_stride)
 	{
+		partial_l1 += (size_t)blockIdx.x * view_stride; partial_ssim += (size_t)blockIdx.x * view_stride; out += 3 * (size_t)blockIdx.x;
 		// 1024 threads, up to 8 partials per thread and sum in flight at once (the kernel is pure latency), then a fixed
 		// shuffle tree per wave and a fixed order over the 16 waves: deterministic
 		__shared__ float r0[16], r1[16];
@@ -727,7 +730,18 @@ extern "C" int fdgs_l1_ssim_loss(const float* partial_l1, const float* partial_s
 	using namespace fdgs;
 	if (!partial_l1 || !partial_ssim || !loss_l1_ssim || num_partials <= 0 || C <= 0 || H <= 0 || W <= 0) return FDGS_ERR_INVALID_ARG;
 	const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial_l1, partial_ssim, num_partials, inv_n, lambda_dssim, loss_l1_ssim);
+	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial_l1, partial_ssim, num_partials, inv_n, lambda_dssim, loss_l1_ssim, 0ll);
+	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
+}
+
+extern "C" int fdgs_l1_ssim_loss_batch(const float* partials, int32_t num_views, int32_t num_partials, int32_t C, int32_t H, int32_t W,
+                                       float lambda_dssim, float* losses, void* stream)
+{
+	using namespace fdgs;
+	if (!partials || !losses || num_views <= 0 || num_partials <= 0 || C <= 0 || H <= 0 || W <= 0) return FDGS_ERR_INVALID_ARG;
+	const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
+	hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(num_views), dim3(1024), 0, (hipStream_t)stream, partials, partials + num_partials, num_partials, inv_n,
+	                   lambda_dssim, losses, 2ll * num_partials);
 	return hipGetLastError() == hipSuccess ? FDGS_OK : FDGS_ERR_HIP;
 }
 

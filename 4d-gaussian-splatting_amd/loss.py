@@ -64,17 +64,21 @@ import os as _os
 ssim_options = {"fused": _os.environ.get("FDGS_SSIM_FUSED", "0") == "1"}
 
 
-def l1_ssim_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor):
+def l1_ssim_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor, parts: torch.Tensor = None):
     """Value and gradient kernels only: returns ``(d(upstream * loss)/d image, handle)``; ``l1_ssim_loss(handle)`` reduces
     the per-tile partial sums to the loss value later (e.g. after the rasterizer backward has been enqueued, so that the
-    small reduction is off the critical path)."""
+    small reduction is off the critical path).  ``parts``: a [2, num_partials] float32 slice to leave the partial sums in (a row of
+    ``partials_buffer``: ``l1_ssim_loss_batch`` then reduces all views of a step in one launch)."""
     if not image.is_cuda or not gt.is_cuda:
         raise RuntimeError("fdgs: l1_ssim_grad needs GPU tensors; there is no CPU path")
     img_c, gt_c = image.contiguous().float(), gt.contiguous().float()
     C, H, W = img_c.shape[-3], img_c.shape[-2], img_c.shape[-1]
     dev = img_c.device
     nparts = _capi.lib.fdgs_l1_ssim_num_partials(C, H, W)
-    parts = torch.empty((2, nparts), dtype=torch.float32, device=dev)
+    if parts is None:
+        parts = torch.empty((2, nparts), dtype=torch.float32, device=dev)
+    elif tuple(parts.shape) != (2, nparts) or not parts.is_contiguous() or parts.dtype != torch.float32:
+        raise RuntimeError("fdgs: parts must be a contiguous float32 [2, %d] tensor" % nparts)
     if ssim_options["fused"]:
         g = torch.empty_like(img_c)
         with torch.cuda.device(dev):
@@ -104,6 +108,24 @@ def l1_ssim_loss(handle) -> torch.Tensor:
                                          _capi.current_stream_handle(dev))
     _capi._check(rc, "fdgs_l1_ssim_loss")
     return out[0]
+
+
+def partials_buffer(num_views: int, C: int, H: int, W: int, device) -> torch.Tensor:
+    """[num_views, 2, num_partials]: one row per view for ``l1_ssim_grad(parts=buffer[v])``."""
+    return torch.empty((num_views, 2, _capi.lib.fdgs_l1_ssim_num_partials(C, H, W)), dtype=torch.float32, device=device)
+
+
+def l1_ssim_loss_batch(buffer: torch.Tensor, handles) -> list:
+    """The loss values of the ``l1_ssim_grad`` calls that left their partial sums in rows 0 .. len(handles) - 1 of ``buffer``: ONE
+    launch (a workgroup per view) instead of one per view; bit-identical to ``l1_ssim_loss`` per handle.  Returns a list of 0-d tensors."""
+    n = len(handles)
+    _parts, nparts, C, H, W, lam = handles[0]
+    dev = buffer.device
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _capi.lib.fdgs_l1_ssim_loss_batch(buffer.data_ptr(), n, nparts, C, H, W, lam, out.data_ptr(), _capi.current_stream_handle(dev))
+    _capi._check(rc, "fdgs_l1_ssim_loss_batch")
+    return [out[v, 0] for v in range(n)]
 
 
 def l1_ssim_value_and_grad(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float, upstream: torch.Tensor):

@@ -21,7 +21,7 @@ import torch
 from . import _capi
 from .fused import raw_backward, raw_forward, raw_preprocess_batch, raw_settings
 from .gaussian_renderer import diff_gaussian_rasterization as _dgr
-from .loss import l1_ssim_grad, l1_ssim_loss
+from .loss import l1_ssim_grad, l1_ssim_loss, l1_ssim_loss_batch, partials_buffer
 from .train_host import allreduce_and_step, allreduce_sh_begin, gather_view_stage_begin, timed_wait
 
 
@@ -75,6 +75,8 @@ class StepPipeline:
         self.overlap_steps = (bool(overlap_steps) and bool(overlap) and int(world_size) == 1 and bool(fuse_sh_adam)
                               and os.environ.get("FDGS_PIPELINE_OVERLAP_STEPS", "1") != "0")
         self.finish_on_F = bool(overlap) and os.environ.get("FDGS_PIPELINE_LOSS_FINISH", "F") == "F"
+        # ... and all views' reductions in ONE launch (fdgs_l1_ssim_loss_batch; FDGS_PIPELINE_LOSS_BATCH=0: one launch per view, A/B)
+        self.loss_batch = self.finish_on_F and os.environ.get("FDGS_PIPELINE_LOSS_BATCH", "1") != "0"
         self._carry = None    # what the model looked like when the last step left its SH update running on stream A
         self.steps_carried = 0
         # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
@@ -107,6 +109,7 @@ class StepPipeline:
         self.sink = model.grad_sink()
         self._up = {}
         self._gacc = None   # persistent, always-zero blend-backward accumulator (no memset per view)
+        self._parts, self._parts_hw = None, None   # [B, 2, num_partials]: the views' partial loss sums (one reduction launch per step)
         self._sh_stage = None   # [B, P, 8]: deferred SH gradient (fdgs_backward_out.sh_stage), flushed once per step
         self._gathered = None   # [B, world, P, 8]: the stages of all ranks (several ranks, gather mode)
 
@@ -206,7 +209,10 @@ class StepPipeline:
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
                 self.sB.wait_event(ev)
-                g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up)
+                if self.loss_batch and (self._parts is None or self._parts.shape[0] != B or self._parts_hw != tuple(color.shape)):
+                    # the views' partial loss sums in one buffer: ONE reduction launch per step (below) instead of one per view
+                    self._parts, self._parts_hw = partials_buffer(B, color.shape[0], color.shape[1], color.shape[2], self.dev), tuple(color.shape)
+                g_color, loss_handle = l1_ssim_grad(color, gts[b], self.lam, up, parts=self._parts[b] if self.loss_batch else None)
                 if self.finish_on_F and b == B - 1:
                     ev_parts = torch.cuda.Event()
                     ev_parts.record(self.sB)   # every view's partial sums are there
@@ -270,7 +276,7 @@ class StepPipeline:
         if self.finish_on_F:
             with torch.cuda.stream(self.sF):
                 self.sF.wait_event(ev_parts)
-                losses = [l1_ssim_loss(h) for h in pend_loss]
+                losses = l1_ssim_loss_batch(self._parts, pend_loss) if self.loss_batch else [l1_ssim_loss(h) for h in pend_loss]
         self._optimizer_tail(rs, fuse, gather, sh_handle, sh_gather, sh_stepped)
         main.wait_stream(self.sB)
         main.wait_stream(self.sF)

@@ -218,6 +218,37 @@ def max_over_ranks(x, world, dev):
     return float(t.item())
 
 
+def reference_kernels_on_this_gpu(scene, dev, passes=20):
+    """Part of the baseline leg: the REFERENCE'S OWN CUDA kernels compiled for gfx950 (oracle/_ref/liboracle_ref_hip.so -- torch.utils.hipify
+    + hipcc on a temporary copy of /root/reference's sources in the build container, oracle/refbuild/build_ref_hip.py; the .so travels, the
+    sources do not) on the same scene, the same four upstream gradients, this GPU: rasterizer forward + backward per image incl. the
+    zero-fills rasterize_points.cu does around them (:80-92, :201-213), synchronised per pass as `loss.backward()` + `optimizer.step()`
+    leave it in the reference's loop.  The like-for-like partner of `raster_images_s`.  None when the library was not built."""
+    from fdgs import synth
+    from oracle import ref_hip
+    if not ref_hip.available():
+        return None
+    g = {k: v.to(dev) for k, v in synth.make_upstream_grads(scene["W"], scene["H"], seed=1, scale=1e-2).items()}
+    ref = ref_hip.RefHip(scene, dev)
+    for _ in range(3):
+        ref.forward()
+        ref.backward(g["grad_color"], g["grad_depth"], g["grad_alpha"], g["grad_flow"])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        ref.forward()
+    t_f = (time.perf_counter() - t0) / passes
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        ref.forward()
+        ref.backward(g["grad_color"], g["grad_depth"], g["grad_alpha"], g["grad_flow"])
+    t_fb = (time.perf_counter() - t0) / passes
+    ref_hip.lib().refhip_free()
+    return {"images_s": round(1.0 / t_fb, 2), "ms_per_image": round(t_fb * 1e3, 3), "forward_ms": round(t_f * 1e3, 3), "num_rendered": int(ref.R),
+            "kind": "reference (its own forward.cu / backward.cu / rasterizer_impl.cu, hipified and compiled for gfx950; hipcub radix sort)",
+            "what": "rasterizer forward + backward of the same %s scene, all four upstream gradients, %d passes on this GPU" % (scene["cfg"].name, passes)}
+
+
 def cpu_baseline(scene, samples):
     """The oracle ("port": scalar C restatement of the reference kernels, OpenMP over Gaussians / tiles)
     timed on this box's host cores on a bounded sample of the same workload: `samples` full rasterizer
@@ -1190,6 +1221,11 @@ def main():
     if world == 1 and args.cpu_samples > 0:
         cb_scene = scene if args.cameras == "axis" else dict(scene, **synth.camera_for("rig0", scene["W"], scene["H"]))
         out["cpu_baseline"] = cpu_baseline(cb_scene, args.cpu_samples)
+        # (the baseline leg's second half: the reference's own kernels on THIS GPU, same scene -- the partner of raster_images_s)
+        ref_gpu = reference_kernels_on_this_gpu(cb_scene, dev)
+        if ref_gpu is not None:
+            out["cpu_baseline"]["reference_kernels_on_this_gpu"] = ref_gpu
+            out["reference_hipified_images_s"] = ref_gpu["images_s"]
     print(json.dumps(out))
 
 

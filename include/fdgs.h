@@ -426,6 +426,11 @@ int fdgs_l1_ssim_value_and_grad(const float* img, const float* gt, int32_t C, in
  * loss_l1_ssim[0] = (1 - lambda) * L1 + lambda * (1 - SSIM), [1] = L1, [2] = SSIM   (device memory, 3 floats). */
 int fdgs_l1_ssim_loss(const float* partial_l1, const float* partial_ssim, int32_t num_partials, int32_t C, int32_t H, int32_t W,
                       float lambda_dssim, float* loss_l1_ssim, void* stream);
+/* The same reduction for every view of an optimizer step in ONE launch (one workgroup per view; bit-identical to num_views calls of
+ * fdgs_l1_ssim_loss): partials = [num_views][2][num_partials] -- view v's partial_l1 at partials + v * 2 * num_partials, its
+ * partial_ssim num_partials floats behind -- losses = [num_views][3]. */
+int fdgs_l1_ssim_loss_batch(const float* partials, int32_t num_views, int32_t num_partials, int32_t C, int32_t H, int32_t W,
+                            float lambda_dssim, float* losses, void* stream);
 
 /* ---- adjacent row: fused Adam over a flat parameter bucket ---------
  * torch.optim.Adam arithmetic (no amsgrad / weight decay) in one streaming pass over four flat fp32

@@ -145,9 +145,25 @@ def test_product_never_imports_the_oracle():
             with open(os.path.join(dirpath, fn)) as f:
                 for ln in f:
                     low = ln.lower()
-                    if "oracle" in low:
-                        assert not any(tok in low for tok in ("import", "#include", "cdll", "dlopen", "liboracle")), \
+                    if "oracle" in low or "ref_hip" in low or "refhip" in low:
+                        assert not any(tok in low for tok in ("import", "#include", "cdll", "dlopen", "liboracle", "ref_hip", "refhip")), \
                             "%s references the oracle: %s" % (fn, ln.strip())
+
+
+def test_only_the_baseline_leg_of_the_bench_touches_the_oracle():
+    """bench.py may use oracle/ in its baseline leg only (cpu_baseline and its GPU half, reference_kernels_on_this_gpu): every import of it
+    sits inside those two functions."""
+    import ast
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        tree = ast.parse(f.read())
+    allowed = {"cpu_baseline", "reference_kernels_on_this_gpu"}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef):
+            for sub in ast.walk(node):
+                if isinstance(sub, ast.ImportFrom) and sub.module and sub.module.split(".")[0] == "oracle":
+                    assert node.name in allowed, "bench.py::%s imports the oracle" % node.name
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any(getattr(n, "module", "") and n.module.split(".")[0] == "oracle" for n in top)
 
 
 def test_fdgs_adam_rejects_what_it_does_not_implement():

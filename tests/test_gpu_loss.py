@@ -196,3 +196,29 @@ def test_one_kernel_value_and_grad_equals_the_two_kernel_path(shape, gpu_device)
     assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-6 * scale
     assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(res[False][1].abs().max())
     assert abs(res[True][2] - res[False][2]) <= 1e-6
+
+
+def test_loss_values_of_a_step_in_one_launch(gpu_device):
+    """fdgs_l1_ssim_loss_batch: the loss-value reductions of all views of an optimizer step in one launch (a workgroup per view) --
+    bit-identical to one fdgs_l1_ssim_loss per view (what fdgs.pipeline.StepPipeline used to enqueue: four one-workgroup launches)."""
+    from fdgs.loss import l1_ssim_grad, l1_ssim_loss, l1_ssim_loss_batch, partials_buffer
+    C, H, W, B = 3, 131, 203, 5
+    g = torch.Generator(device="cpu").manual_seed(11)
+    imgs = [torch.rand(C, H, W, generator=g).to(gpu_device) for _ in range(B)]
+    gts = [torch.rand(C, H, W, generator=g).to(gpu_device) for _ in range(B)]
+    up = torch.full((1,), 0.25, device=gpu_device)
+    buf = partials_buffer(B, C, H, W, gpu_device)
+    singles, handles, grads = [], [], []
+    for v in range(B):
+        g1, h1 = l1_ssim_grad(imgs[v], gts[v], 0.2, up)
+        singles.append(l1_ssim_loss(h1))
+        g2, h2 = l1_ssim_grad(imgs[v], gts[v], 0.2, up, parts=buf[v])
+        handles.append(h2)
+        grads.append((g1, g2))
+    batch = l1_ssim_loss_batch(buf, handles)
+    torch.cuda.synchronize()
+    for v in range(B):
+        assert torch.equal(batch[v], singles[v]) and torch.equal(*grads[v]), v
+    assert len({float(x) for x in batch}) == B
+    with pytest.raises(RuntimeError):
+        l1_ssim_grad(imgs[0], gts[0], 0.2, up, parts=buf[0][:, :-1])
