@@ -62,11 +62,17 @@ class FdgsBackwardIn(_Sized):
                 ("image_buffer", _fp), ("num_rendered", C.c_int32)]
 
 
+class FdgsGeometryAdam(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("flat", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp),
+                ("lr_means3D", C.c_float), ("lr_opacities", C.c_float), ("lr_ts", C.c_float), ("lr_scales", C.c_float), ("lr_scales_t", C.c_float),
+                ("lr_rotations", C.c_float), ("lr_rotations_r", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32)]
+
+
 class FdgsBackwardOut(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("dL_dmeans2D", _fp), ("dL_dcolors", _fp), ("dL_dopacity", _fp), ("dL_dmeans3D", _fp),
                 ("dL_dcov3D", _fp), ("dL_dsh", _fp), ("dL_dflows", _fp), ("dL_dts", _fp), ("dL_dscales", _fp),
                 ("dL_dscales_t", _fp), ("dL_drotations", _fp), ("dL_drotations_r", _fp), ("accumulate", C.c_int32),
-                ("grad_accum", _fp), ("grad_accum_clean", C.c_int32), ("sh_stage", _fp), ("stage_mask", C.c_int32)]
+                ("grad_accum", _fp), ("grad_accum_clean", C.c_int32), ("sh_stage", _fp), ("stage_mask", C.c_int32), ("adam", C.POINTER(FdgsGeometryAdam))]
 
 
 class FdgsDebugView(_Sized):

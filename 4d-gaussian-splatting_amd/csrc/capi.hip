@@ -618,6 +618,18 @@ extern "C" int fdgs_rasterize_backward(const fdgs_scene* scene, const fdgs_backw
 	CHECK_STRUCT(scene, fdgs_scene);
 	CHECK_STRUCT(in, fdgs_backward_in);
 	CHECK_STRUCT(out, fdgs_backward_out);
+	if (out->adam != nullptr)
+	{
+		const fdgs_geometry_adam* g = out->adam;
+		if (g->struct_size != sizeof(fdgs_geometry_adam)) return fail(FDGS_ERR_INVALID_ARG, "fdgs_geometry_adam.struct_size is %u, expected %zu", (unsigned)g->struct_size, sizeof(fdgs_geometry_adam));
+		if (!scene->raw_params || scene->cov3D_precomp || !scene->scales || !scene->rotations || !scene->ts || !scene->scales_t || !scene->rotations_r)
+			return fail(FDGS_ERR_INVALID_ARG, "fdgs_backward_out.adam needs a raw_params scene that holds all seven geometry tensors (rot_4d): an optimizer steps the "
+			                                  "parameters a 3D scene leaves out as well, this call could not");
+		if (!g->flat || !g->exp_avg || !g->exp_avg_sq || g->step < 1 || !out->dL_dopacity || !out->dL_dmeans3D || !out->dL_dscales || !out->dL_drotations
+		    || (scene->ts && !out->dL_dts) || (scene->scales_t && !out->dL_dscales_t) || (scene->rotations_r && !out->dL_drotations_r))
+			return fail(FDGS_ERR_INVALID_ARG, "fdgs_backward_out.adam: flat / exp_avg / exp_avg_sq, step >= 1 and a gradient array for every geometry parameter are required");
+		if ((out->stage_mask & 3) == 1) return fail(FDGS_ERR_INVALID_ARG, "fdgs_backward_out.adam belongs to the call that runs the geometry backward (stage_mask 0, 2 or 3)");
+	}
 	int rc = check_scene(scene);
 	if (rc != FDGS_OK) return rc;
 	const fdgs_scene& s = *scene;

@@ -41,6 +41,12 @@ namespace fdgs
 		int rezero; /* leave the record zero for the next backward (fdgs_backward_out.grad_accum_clean) */
 		float *dL_dmean2D, *dL_dcolor, *dL_dflows;
 		float *dL_dopacity, *dL_dmeans, *dL_dcov3D, *dL_dts, *dL_dscale, *dL_dscale_t, *dL_drot, *dL_drot_r;
+		// fdgs_backward_out.adam: the Adam step of the geometry parameters with the gradient completed here
+		int adam;
+		const float* means_in;                   // the means3D PARAMETER (a.means is the forward's shifted out_means3D)
+		float *ad_flat, *ad_m, *ad_v;
+		float ad_lr[7];                          // x 1 / (1 - beta1^step): means3D, opacities, ts, scales, scales_t, rotations, rotations_r
+		float ad_b1, ad_b2, ad_eps, ad_inv_sqrt_bc2;
 	};
 
 	__device__ __forceinline__ float3 b_ld3(const float* p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -343,6 +349,32 @@ namespace fdgs
 #pragma unroll
 			for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
 		}
+		if (a.adam)
+		{
+			// The last view of an optimizer step: complete the gradient (this view's, plus what the earlier views left when accumulating)
+			// and take the parameter's Adam step with it -- every Gaussian, visible here or not (torch.optim.Adam moves a parameter whose
+			// gradient is zero by its first moment).  Same device function as adam.hip: bit-identical to the separate launch.
+			const auto step = [&](const float* param, float* grad, const size_t e, const float g_view, const float lr)
+			{
+				const float total = a.accum ? grad[e] + g_view : g_view;
+				if (!a.accum || visible) grad[e] = total;
+				if (param == nullptr) return;   // (a gradient array without its parameter: a 3D scene's dL_dts / dL_dscale_t / dL_drot_r of the common sink)
+				float* p = const_cast<float*>(param) + e;
+				const size_t off = (size_t)(p - a.ad_flat);
+				float pv = *p, m = a.ad_m[off], v = a.ad_v[off];
+				adam_update(pv, m, v, total, lr, a.ad_b1, a.ad_b2, a.ad_eps, a.ad_inv_sqrt_bc2);
+				a.ad_m[off] = m; a.ad_v[off] = v; *p = pv;
+			};
+			const size_t i = (size_t)idx;
+			step(a.opacities, a.dL_dopacity, i, g_opacity, a.ad_lr[1]);
+			step(a.means_in, a.dL_dmeans, 3 * i, dmean.x, a.ad_lr[0]); step(a.means_in, a.dL_dmeans, 3 * i + 1, dmean.y, a.ad_lr[0]); step(a.means_in, a.dL_dmeans, 3 * i + 2, dmean.z, a.ad_lr[0]);
+			if (a.dL_dts) step(a.ts, a.dL_dts, i, dts, a.ad_lr[2]);
+			if (a.dL_dscale) { step(a.scales, a.dL_dscale, 3 * i, dscale.x, a.ad_lr[3]); step(a.scales, a.dL_dscale, 3 * i + 1, dscale.y, a.ad_lr[3]); step(a.scales, a.dL_dscale, 3 * i + 2, dscale.z, a.ad_lr[3]); }
+			if (a.dL_dscale_t) step(a.scales_t, a.dL_dscale_t, i, dscale_t, a.ad_lr[4]);
+			if (a.dL_drot) { step(a.rotations, a.dL_drot, 4 * i, drot.x, a.ad_lr[5]); step(a.rotations, a.dL_drot, 4 * i + 1, drot.y, a.ad_lr[5]); step(a.rotations, a.dL_drot, 4 * i + 2, drot.z, a.ad_lr[5]); step(a.rotations, a.dL_drot, 4 * i + 3, drot.w, a.ad_lr[5]); }
+			if (a.dL_drot_r) { step(a.rotations_r, a.dL_drot_r, 4 * i, drot_r.x, a.ad_lr[6]); step(a.rotations_r, a.dL_drot_r, 4 * i + 1, drot_r.y, a.ad_lr[6]); step(a.rotations_r, a.dL_drot_r, 4 * i + 2, drot_r.z, a.ad_lr[6]); step(a.rotations_r, a.dL_drot_r, 4 * i + 3, drot_r.w, a.ad_lr[6]); }
+			return;
+		}
 		if (a.accum)
 		{
 			// gradient accumulation over the views of one optimizer step: add into the parameter gradients
@@ -397,6 +429,17 @@ namespace fdgs
 		a.dL_dopacity = out.dL_dopacity; a.dL_dmeans = out.dL_dmeans3D; a.dL_dcov3D = out.dL_dcov3D;
 		a.dL_dts = out.dL_dts; a.dL_dscale = out.dL_dscales; a.dL_dscale_t = out.dL_dscales_t;
 		a.dL_drot = out.dL_drotations; a.dL_drot_r = out.dL_drotations_r;
+		a.adam = 0; a.means_in = s.means3D; a.ad_flat = a.ad_m = a.ad_v = nullptr;
+		if (out.adam != nullptr)
+		{
+			const fdgs_geometry_adam& g = *out.adam;
+			const double bc1 = 1.0 - pow((double)g.beta1, (double)g.step), bc2 = 1.0 - pow((double)g.beta2, (double)g.step);   // as fdgs_adam_step
+			const float inv_bc1 = (float)(1.0 / bc1);
+			a.adam = 1; a.ad_flat = g.flat; a.ad_m = g.exp_avg; a.ad_v = g.exp_avg_sq;
+			const float lr[7] = { g.lr_means3D, g.lr_opacities, g.lr_ts, g.lr_scales, g.lr_scales_t, g.lr_rotations, g.lr_rotations_r };
+			for (int k = 0; k < 7; k++) a.ad_lr[k] = lr[k] * inv_bc1;
+			a.ad_b1 = g.beta1; a.ad_b2 = g.beta2; a.ad_eps = g.eps; a.ad_inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+		}
 		if (s.P >= (1 << 20)) hipLaunchKernelGGL(preprocess_bwd_kernel_w4, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		else hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();

@@ -51,10 +51,11 @@ def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, sc
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
                  prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=None, after_sh=None,
-                 sh_stage=None, begin_only=False, per_view_outputs=True):
+                 sh_stage=None, begin_only=False, per_view_outputs=True, geometry_adam=None):
     """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple.
     ``begin_only``: only the blend backward (``_C.backward_begin``): returns the pending call for ``_C.sh_backward_batch`` /
-    ``_C.backward_finish``.  ``per_view_outputs=False``: dL_dcolors / dL_dcov3D / dL_dflows are not written (None in the tuple)."""
+    ``_C.backward_finish``.  ``per_view_outputs=False``: dL_dcolors / dL_dcov3D / dL_dflows are not written (None in the tuple).
+    ``geometry_adam``: see ``_C.rasterize_gaussians_backward`` (the geometry parameters' Adam step inside the geometry backward)."""
     e = torch.Tensor([])
     args = (rs.bg, means3D, out_means3D, radii, e, e, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw,
             rotation_r_raw, rs.scale_modifier, e, prefilter_var, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
@@ -64,7 +65,7 @@ def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_r
         return _C.backward_begin(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum, sh_stage=sh_stage,
                                  per_view_outputs=per_view_outputs)
     return _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum,
-                                           after_sh=after_sh, sh_stage=sh_stage, per_view_outputs=per_view_outputs)
+                                           after_sh=after_sh, sh_stage=sh_stage, per_view_outputs=per_view_outputs, geometry_adam=geometry_adam)
 
 
 def raw_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0):

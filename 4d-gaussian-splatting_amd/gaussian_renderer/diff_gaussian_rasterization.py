@@ -238,7 +238,7 @@ class _NativeRasterizer:
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
                                      imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False, grad_accum=None,
-                                     after_sh=None, sh_stage=None, per_view_outputs=True, _phase=None):
+                                     after_sh=None, sh_stage=None, per_view_outputs=True, geometry_adam=None, _phase=None):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
@@ -250,7 +250,10 @@ class _NativeRasterizer:
         fdgs_backward_out.stage_mask): dL_dsh is final at that point, so a data-parallel caller can start its all-reduce;
         ``sh_stage``: a [P,8] float32 scratch tensor -> deferred SH gradient (fdgs_backward_out.sh_stage): dL_dsh is not
         touched by this call, ``_capi.sh_flush`` builds it from the stages of all views of the step;
-        ``per_view_outputs=False``: dL_dcolors, dL_dcov3D and dL_dflows are not written (NULL at the C ABI) and come back as None."""
+        ``per_view_outputs=False``: dL_dcolors, dL_dcov3D and dL_dflows are not written (NULL at the C ABI) and come back as None;
+        ``geometry_adam``: a callable evaluated right before the geometry backward is enqueued (after ``after_sh``) that returns None or
+        dict(flat, exp_avg, exp_avg_sq, lr={means3D, opacities, ts, scales, scales_t, rotations, rotations_r}, betas, eps, step): the
+        geometry backward then also takes the Adam step of the geometry parameters (fdgs_backward_out.adam; raw_params only)."""
         dev = means3D.device
         # The reference always receives four dense tensors (autograd materialises zeros).  Here an image gradient may
         # be None = "no upstream gradient": the kernels then skip that term (colour-only backward when only
@@ -315,8 +318,22 @@ class _NativeRasterizer:
             _capi._check(rc, "fdgs_rasterize_backward")
             return {"scene": scene, "keep": keep, "bin": bin_, "bout": bout, "g": g, "dev": dev, "clean": clean, "grad_accum": grad_accum,
                     "alive": (gin, radii_c, om_c, geomBuffer, binningBuffer, imageBuffer, sh_stage)}
+        adam_keep = None
+
+        def attach_adam():
+            ga = geometry_adam() if geometry_adam is not None else None
+            if ga is None:
+                return None
+            lr = ga["lr"]
+            st = _capi.FdgsGeometryAdam(_capi._ptr(ga["flat"]), _capi._ptr(ga["exp_avg"]), _capi._ptr(ga["exp_avg_sq"]), float(lr["means3D"]),
+                                        float(lr["opacities"]), float(lr.get("ts", 0.0)), float(lr["scales"]), float(lr.get("scales_t", 0.0)),
+                                        float(lr["rotations"]), float(lr.get("rotations_r", 0.0)), float(ga["betas"][0]), float(ga["betas"][1]),
+                                        float(ga["eps"]), int(ga["step"]))
+            bout.adam = C.pointer(st)
+            return (st, ga)
         with torch.cuda.device(dev):
             if after_sh is None:
+                adam_keep = attach_adam()
                 rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
                                                        _capi.current_stream_handle(dev))
             else:
@@ -326,8 +343,10 @@ class _NativeRasterizer:
                 if rc == 0:
                     after_sh()
                     bout.stage_mask = 2
+                    adam_keep = attach_adam()
                     rc = _capi.lib.fdgs_rasterize_backward(C.byref(scene), C.byref(bin_), C.byref(bout),
                                                            _capi.current_stream_handle(dev))
+        del adam_keep
         if rc != 0 and clean:
             # a failed call may have left partial sums behind: restore the caller's "all zero on entry" invariant
             grad_accum.zero_()

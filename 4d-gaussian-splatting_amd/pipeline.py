@@ -77,6 +77,11 @@ class StepPipeline:
         self.finish_on_F = bool(overlap) and os.environ.get("FDGS_PIPELINE_LOSS_FINISH", "F") == "F"
         # ... and all views' reductions in ONE launch (fdgs_l1_ssim_loss_batch; FDGS_PIPELINE_LOSS_BATCH=0: one launch per view, A/B)
         self.loss_batch = self.finish_on_F and os.environ.get("FDGS_PIPELINE_LOSS_BATCH", "1") != "0"
+        # one rank, fused SH update: the Adam step of the 17 geometry parameters per Gaussian is taken INSIDE the last view's geometry
+        # backward (fdgs_backward_out.adam: the kernel has just completed their gradient) instead of by a launch of its own at the very end
+        # of the step (FDGS_PIPELINE_GEO_ADAM=0: the separate launch, A/B); bit-identical parameters and moments
+        self.fuse_geo_adam = os.environ.get("FDGS_PIPELINE_GEO_ADAM", "1") != "0"
+        self._geo_adam_done = False
         self._carry = None    # what the model looked like when the last step left its SH update running on stream A
         self.steps_carried = 0
         # several ranks, measurement aid: with ``exchange_pairs`` a list, every wait of stream B for a collective at the end of the step
@@ -259,10 +264,24 @@ class StepPipeline:
                                            rs.force_sh_3d, _dgr.analytic_sh_gradients())
                         if self.world > 1:
                             sh_handle.append(allreduce_sh_begin(m, self.world))
+                geo_adam = None
+                self._geo_adam_done = False
+                if b == B - 1 and fuse and self.sB is not self.sF and self.fuse_geo_adam and m.rot_4d and m.gaussian_dim == 4:
+                    def geo_adam():
+                        # (called after after_sh: the step count is this step's, and it is known whether the fused SH update ran --
+                        # the tail's fall-back, flush + one Adam over the whole bucket, must not meet parameters already stepped)
+                        if not (sh_stepped and sh_stepped[0]):
+                            return None
+                        self._geo_adam_done = True
+                        lr = {s_["name"]: s_["lr"] for s_ in self.opt.named_segments()}
+                        return dict(flat=m.flat, exp_avg=self.opt.exp_avg, exp_avg_sq=self.opt.exp_avg_sq, betas=self.opt.betas, eps=self.opt.eps,
+                                    step=self.opt.step_count,
+                                    lr=dict(means3D=lr["_xyz"], opacities=lr["_opacity"], ts=lr["_t"], scales=lr["_scaling"], scales_t=lr["_scaling_t"],
+                                            rotations=lr["_rotation"], rotations_r=lr["_rotation_r"]))
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
                                      self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh,
-                                     sh_stage=self._sh_stage[b] if defer_sh else None, per_view_outputs=False)
+                                     sh_stage=self._sh_stage[b] if defer_sh else None, per_view_outputs=False, geometry_adam=geo_adam)
                 # the small reduction of the loss VALUE: behind the backward (nothing of the step waits for it) -- or, with two streams, all
                 # views' reductions on stream F behind its last forward (below): stream B's chain is the step's critical path, and 4 x ~6 us
                 # of a one-workgroup kernel were part of it
@@ -303,7 +322,8 @@ class StepPipeline:
                     self.opt.step_count += 1
                     sh_stepped.append(self.opt.step_sh_staged(self._sh_stage, rs, _dgr.analytic_sh_gradients()))
                 if sh_stepped[0]:
-                    self.opt.step_range(0, m.offsets["_features"][0])
+                    if not self._geo_adam_done:     # (else: taken inside the last view's geometry backward)
+                        self.opt.step_range(0, m.offsets["_features"][0])
                 else:   # layout the fused kernel does not take: the two passes
                     _capi.sh_flush(self._sh_stage, self.sink["dL_dsh"], rs.sh_degree, rs.sh_degree_t, rs.gaussian_dim,
                                    rs.force_sh_3d, _dgr.analytic_sh_gradients())

@@ -344,6 +344,11 @@ class FlatAdam:
         self._native = None
         self._lr_vec = None
 
+    def named_segments(self):
+        """The segment table with the parameter tensor each segment belongs to (``name``)."""
+        by_range = {tuple(v): k for k, v in self.model.offsets.items()}
+        return [dict(s, name=by_range[(s["begin"], s["end"])]) for s in self.segments]
+
     def set_lr(self, name: str, lr: float, lr_head: float = None):
         """Learning rate of one parameter tensor (the reference's ``param_group['lr'] = lr``, gaussian_model.py:359-365)."""
         b, e = self.model.offsets[name]

@@ -181,6 +181,18 @@ typedef struct fdgs_forward_out
 	                         of a step).  Same device as the call's stream */
 } fdgs_forward_out;
 
+/* fdgs_backward_out.adam: the scene's geometry tensors are slices of ONE flat parameter buffer `flat`; exp_avg / exp_avg_sq are
+   torch.optim.Adam's moments in the same layout (a parameter at flat + k has its moments at exp_avg + k, exp_avg_sq + k).  Learning
+   rates per tensor (arguments/__init__.py:84-92), `step` >= 1 = the step being taken (bias corrections as fdgs_adam_step). */
+typedef struct fdgs_geometry_adam
+{
+	uint32_t struct_size;
+	float* flat; float* exp_avg; float* exp_avg_sq;
+	float lr_means3D, lr_opacities, lr_ts, lr_scales, lr_scales_t, lr_rotations, lr_rotations_r;
+	float beta1, beta2, eps;
+	int32_t step;
+} fdgs_geometry_adam;
+
 /* Upstream gradients (d loss / d forward outputs).  Any of the four image gradients may be NULL = "this output
    has no upstream gradient" (treated as zero; at least one must be given).  With only dL_dout_color given the
    backward blend runs its colour-only variant. */
@@ -241,6 +253,11 @@ typedef struct fdgs_backward_out
 	                             + 4 (5 = blend backward only): the SH backward of this view is left to fdgs_sh_backward_batch, which
 	                             does it for all views of the optimizer step in one pass over the coefficients; the view's
 	                             geometry backward (2) follows after that call.  Needs sh_stage and a grad_accum of the view's own. */
+	const struct fdgs_geometry_adam* adam; /* NULL, or (raw_params scenes with all seven geometry tensors, i.e. rot_4d; the LAST view of an optimizer step): the geometry backward also TAKES the
+	                             Adam step of the 17 geometry parameters of every Gaussian -- means3D, opacities, ts, scales, scales_t, rotations,
+	                             rotations_r as the scene points at them -- with the gradient it has just completed (this view's, added to what
+	                             the gradient arrays hold when accumulate = 1; the arrays still receive the sum).  Bit-identical to
+	                             fdgs_adam_step over those tensors afterwards; saves that launch and its 28 bytes per parameter. */
 } fdgs_backward_out;
 
 /* Forward pass: preprocess -> tile count -> tile scan -> tile scatter -> per-tile local sort (+ ranges) -> per-tile

@@ -713,3 +713,65 @@ def test_backward_without_the_per_view_outputs(gpu_device):
         assert torch.isfinite(got).all(), k
         sc = max(1e-6, float(want.abs().max()))
         assert float((got - want).abs().max()) <= 1e-3 * sc, k   # (atomics order through the covariance chain: as test_sh_backward_batch_matches_per_view)
+
+
+@pytest.mark.parametrize("cfg", [synth.SceneConfig("ga4", 20012, 320, 240, 3, 2, 0.015, 10.0, True, 4, False),
+                                 synth.SceneConfig("ga3", 9004, 200, 160, 2, 0, 0.03, 1.0, False, 3, False)], ids=["rot4d", "dim3"])
+def test_geometry_adam_inside_the_last_views_backward_is_the_separate_step(cfg, gpu_device):
+    """fdgs_backward_out.adam: the last view's geometry backward takes the Adam step of the 17 geometry parameters per Gaussian with the
+    gradient it has just completed (here: accumulated over two views).  The gradient bucket still receives the sums, so the separate
+    launch can be replayed on a copy of the state before: parameters and both moments must come out bit for bit the same -- for the
+    Gaussians the last view did not see too (non-zero moments move a parameter whose gradient is zero)."""
+    from fdgs import train_host
+    from fdgs.fused import raw_backward, raw_forward, raw_settings
+    from fdgs.loss import l1_ssim_grad
+    scene = synth.make_scene(cfg, seed=41, pose="rig3")
+    scene["means3D"][::7, 2] = -9.0                       # every seventh Gaussian behind the camera: never visible
+    needs_all_seven = not (cfg.rot_4d and cfg.gaussian_dim == 4)   # a 3D scene leaves _t / _scaling_t / _rotation_r out of the call: refused
+    model = train_host.GaussianParams(scene, gpu_device)
+    opt = train_host.make_optimizer(model)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    opt.exp_avg.copy_((1e-3 * torch.randn(opt.exp_avg.shape, generator=g)).to(gpu_device))
+    opt.exp_avg_sq.copy_((1e-6 * torch.rand(opt.exp_avg_sq.shape, generator=g)).to(gpu_device))
+    opt.step_count = 6
+    before = (model.flat.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    pipe, bg = train_host.PipelineFlags(), scene["bg"].to(gpu_device)
+    cams = [train_host.SyntheticCamera(scene, gpu_device, timestamp=(b + 0.5) / 2 * scene["time_duration"]) for b in range(2)]
+    up = torch.full((1,), 0.5, device=gpu_device)
+    sink = model.grad_sink()
+    feat = model.offsets["_features"][0]
+    gacc = torch.zeros((model.P, 16), device=gpu_device)
+    for b, cam in enumerate(cams):
+        rs, (xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv) = raw_settings(cam, model, pipe, bg)
+        (R, color, flow, depth, T, radii, geom, binb, img, _c, om) = raw_forward(rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv)
+        g_color, _h = l1_ssim_grad(color, torch.rand(3, cfg.H, cfg.W, generator=g).to(gpu_device), 0.2, up)
+
+        def geo_adam():
+            opt.step_count += 1
+            lr = {s_["name"]: s_["lr"] for s_ in opt.named_segments()}
+            return dict(flat=model.flat, exp_avg=opt.exp_avg, exp_avg_sq=opt.exp_avg_sq, betas=opt.betas, eps=opt.eps, step=opt.step_count,
+                        lr=dict(means3D=lr["_xyz"], opacities=lr["_opacity"], ts=lr["_t"], scales=lr["_scaling"], scales_t=lr["_scaling_t"],
+                                rotations=lr["_rotation"], rotations_r=lr["_rotation_r"]))
+        if b == 1 and needs_all_seven:
+            with pytest.raises(Exception, match="all seven geometry tensors"):
+                raw_backward(rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img, g_color, None, None, None,
+                             sink, True, grad_accum=gacc, geometry_adam=geo_adam)
+            assert float(gacc.abs().max()) == 0.0
+            return
+        raw_backward(rs, xyz, om, radii, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, pv, geom, R, binb, img, g_color, None, None, None,
+                     sink, b > 0, grad_accum=gacc, geometry_adam=geo_adam if b == 1 else None)
+    torch.cuda.synchronize()
+    got = (model.flat.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    invisible = (radii == 0)
+    assert int(invisible.sum()) >= model.P // 8
+    # replay: the state before + the gradient sums the kernels left in the bucket -> the separate Adam launch over the geometry segment
+    with torch.no_grad():
+        model.flat.copy_(before[0])
+    opt.exp_avg.copy_(before[1]); opt.exp_avg_sq.copy_(before[2])
+    opt.step_range(0, feat)
+    torch.cuda.synchronize()
+    for name, a, b_ in (("parameters", got[0][:feat], model.flat.detach()[:feat]), ("exp_avg", got[1][:feat], opt.exp_avg[:feat]), ("exp_avg_sq", got[2][:feat], opt.exp_avg_sq[:feat])):
+        assert torch.equal(a, b_), "%s: the fused geometry Adam differs from the separate launch (max %g)" % (name, float((a - b_).abs().max()))
+    assert torch.equal(got[0][feat:], before[0][feat:])              # the SH coefficients are not this call's business
+    moved = (got[0][:feat] != before[0][:feat]).float().mean().item()
+    assert moved > 0.95, moved
