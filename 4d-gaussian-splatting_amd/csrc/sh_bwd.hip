@@ -386,6 +386,7 @@ namespace fdgs
 		return per_cu * cus;
 	}
 
+
 	hipError_t launch_sh_bwd(const fdgs_scene& s, const fdgs_backward_in& in, const fdgs_backward_out& out, const char* geom, hipStream_t stream)
 	{
 		if (s.shs == nullptr || s.M <= 0) return hipSuccess;

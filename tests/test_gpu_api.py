@@ -775,3 +775,4 @@ def test_geometry_adam_inside_the_last_views_backward_is_the_separate_step(cfg, 
     assert torch.equal(got[0][feat:], before[0][feat:])              # the SH coefficients are not this call's business
     moved = (got[0][:feat] != before[0][:feat]).float().mean().item()
     assert moved > 0.95, moved
+
