@@ -163,22 +163,32 @@ namespace fdgs
 	                                                 int first_coeff, unsigned long long alive_mask, int lane)
 	{
 		constexpr int CH = 12;                     // float4 chunks per Gaussian: 16 coefficients x 3 floats / 4
+#ifndef FDGS_PRE_BATCH
+#define FDGS_PRE_BATCH 12                      // float4 per lane in flight (A/B: 6 = two batches per block, fewer staging registers)
+#endif
+		constexpr int BATCH = FDGS_PRE_BATCH;
 		const size_t row_floats = (size_t)3 * M;
-		float4 v[CH];
 #pragma unroll
-		for (int i = 0; i < CH; i++)
+		for (int b = 0; b < CH / BATCH; b++)
 		{
-			const int c = i * WAVE + lane, g = c / CH, q = c - g * CH;
-			const bool ok = g0 + g < P && ((alive_mask >> g) & 1ull);
-			v[i] = ok ? *reinterpret_cast<const float4*>(shs + (size_t)(g0 + g) * row_floats + (size_t)first_coeff * 3 + 4 * q)
-			          : make_float4(0.f, 0.f, 0.f, 0.f);
-		}
+			float4 v[BATCH];
 #pragma unroll
-		for (int i = 0; i < CH; i++)
-		{
-			const int c = i * WAVE + lane, g = c / CH, q = c - g * CH;
-			float* d = tile + g * SH_STRIDE + 4 * q;
-			d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+			for (int j = 0; j < BATCH; j++)
+			{
+				const int i = b * BATCH + j;
+				const int c = i * WAVE + lane, g = c / CH, q = c - g * CH;
+				const bool ok = g0 + g < P && ((alive_mask >> g) & 1ull);
+				v[j] = ok ? *reinterpret_cast<const float4*>(shs + (size_t)(g0 + g) * row_floats + (size_t)first_coeff * 3 + 4 * q)
+				          : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+#pragma unroll
+			for (int j = 0; j < BATCH; j++)
+			{
+				const int i = b * BATCH + j;
+				const int c = i * WAVE + lane, g = c / CH, q = c - g * CH;
+				float* d = tile + g * SH_STRIDE + 4 * q;
+				d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+			}
 		}
 	}
 	__device__ __forceinline__ void stage_sh_block(float* __restrict__ tile, const float* __restrict__ shs, int g0, int P, int M,
