@@ -30,6 +30,29 @@ namespace fdgs
 	// gathered by both blend kernels (one record instead of the reference's four arrays
 	// means2D / conic_opacity / rgb / depths + the flow input):
 	//   a = (x, y, conic.x, conic.y)   b = (conic.z, opacity, r, g)   c = (b, depth, flow.x, flow.y)
+	// Loads / stores of data that is touched ONCE per optimizer step and is larger than the 256 MB Infinity Cache -- the two Adam moments
+	// of the SH coefficients (0.69 GB at C3, 0.77 GB at C5): non-temporal, so that they neither wait for cache lines nor push out what
+	// IS used again (the coefficients themselves -- the next forward reads them -- stay ordinary accesses).  Measured on MI355X
+	// (profiles/HISTORY.md, round 6): fused SH flush + Adam 214 -> 180 us (1.08 GB: 6.0 TB/s), step +1.5 % at C3, +2.3 % at C5;
+	// coefficients non-temporal as well: 190 us; the GEOMETRY parameters' moments (41 MB at C3: they live in that cache from step to
+	// step) non-temporal: step -1 ... -2 %, left alone.  -DFDGS_STREAM_PLAIN: ordinary accesses (A/B).
+#ifndef FDGS_STREAM_PLAIN
+	typedef float fdgs_v4f __attribute__((ext_vector_type(4)));
+	__device__ __forceinline__ float4 stream_ld(const float4* p)
+	{
+		const fdgs_v4f v = __builtin_nontemporal_load(reinterpret_cast<const fdgs_v4f*>(p));
+		return make_float4(v.x, v.y, v.z, v.w);
+	}
+	__device__ __forceinline__ void stream_st(float4* p, float4 x)
+	{
+		fdgs_v4f v = { x.x, x.y, x.z, x.w };
+		__builtin_nontemporal_store(v, reinterpret_cast<fdgs_v4f*>(p));
+	}
+#else
+	__device__ __forceinline__ float4 stream_ld(const float4* p) { return *p; }
+	__device__ __forceinline__ void stream_st(float4* p, float4 x) { *p = x; }
+#endif
+
 	struct GeomLayout
 	{
 		size_t records, depths, cov3D, tiles_touched, rect, clamped;

@@ -666,7 +666,10 @@ namespace fdgs
 	constexpr int SHF_GPW = 32;
 	constexpr int SHF_ACT = 144;                // floats of the three coefficient blocks that can be active
 	constexpr int SHF_STRIDE = SHF_ACT + 1;     // odd: lane-per-row accesses are conflict free
-	constexpr int SHF_BATCH = 6;                // float4 chunks per lane whose p / m / v loads are in flight together
+#ifndef FDGS_SHF_BATCH
+#define FDGS_SHF_BATCH 6
+#endif
+	constexpr int SHF_BATCH = FDGS_SHF_BATCH;   // float4 chunks per lane whose p / m / v loads are in flight together
 
 	struct ShFlushArgs
 	{
@@ -762,8 +765,8 @@ namespace fdgs
 					{
 						const size_t o = (size_t)(g0 + og[i]) * row_floats + 4 * oq[i];
 						pp[i] = *reinterpret_cast<const float4*>(a.p + o);
-						mm[i] = *reinterpret_cast<const float4*>(a.m + o);
-						vv[i] = *reinterpret_cast<const float4*>(a.v + o);
+						mm[i] = stream_ld(reinterpret_cast<const float4*>(a.m + o));   // the moments: once per step, non-temporal (fdgs_common.h)
+						vv[i] = stream_ld(reinterpret_cast<const float4*>(a.v + o));
 					}
 				}
 #pragma unroll
@@ -787,8 +790,8 @@ namespace fdgs
 							const float lr = (e0 == 0 && e < 3) ? a.k.lr_head_bc1 : a.k.lr_bc1;
 							adam_update(pe[e], me[e], ve[e], ge[e], lr, a.k.b1, a.k.b2, a.k.eps, a.k.inv_sqrt_bc2);
 						}
-						*reinterpret_cast<float4*>(a.m + o) = make_float4(me[0], me[1], me[2], me[3]);
-						*reinterpret_cast<float4*>(a.v + o) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+						stream_st(reinterpret_cast<float4*>(a.m + o), make_float4(me[0], me[1], me[2], me[3]));
+						stream_st(reinterpret_cast<float4*>(a.v + o), make_float4(ve[0], ve[1], ve[2], ve[3]));
 						*reinterpret_cast<float4*>(a.p + o) = make_float4(pe[0], pe[1], pe[2], pe[3]);
 						if (a.dL_dsh) *reinterpret_cast<float4*>(a.dL_dsh + o) = make_float4(ge[0], ge[1], ge[2], ge[3]);
 					}

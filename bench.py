@@ -405,6 +405,82 @@ def models_touched():
         p.barrier()
 
 
+def step_end_stages(dev, P, M, B, W, H, D, D_t, gaussian_dim, force_sh_3d, iters=30, workload=None):
+    """The stages of a training step that are NOT inside the rasterizer's profile table: the fused SH flush + Adam of the SH coefficients
+    (fdgs_adam_step_sh: the step's one pass over 89 % of the parameters), the Adam step of the 17 geometry floats per Gaussian
+    (fdgs_adam_step) and the fused L1 + SSIM loss (value partials + gradient, two launches) -- each timed ALONE with HIP events on
+    buffers of the workload's size (not the model's: nothing of the run is touched), with its algorithmic bytes
+    and the fraction of the HBM peak they make.  `working_set_bytes` says whether the launch can live in the 256 MB Infinity Cache
+    from one iteration to the next (the geometry Adam at C3 does: its figure is not an HBM figure)."""
+    from fdgs import _capi
+    from fdgs.loss import l1_ssim_grad
+    out = {}
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / n
+
+    def entry(ms, algo, working):
+        return {"ms": round(ms, 4), "algo_bytes": int(algo), "gbps": round(algo / (ms * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "working_set_bytes": int(working)}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    if M > 0 and (3 * M) % 4 == 0:
+        st = torch.randn(B, P, 8, generator=g)
+        st[:, :, 0:3][torch.rand(B, P, generator=g) < 0.6] = 0     # 40 % of the Gaussians live per view, as on C3
+        st = st.to(dev)
+        prm = torch.randn(P, M, 3, device=dev)
+        m1, m2 = torch.zeros_like(prm), torch.zeros_like(prm)
+        ms = timed(lambda: _capi.adam_step_sh(prm, m1, m2, st, D, D_t, gaussian_dim, force_sh_3d, False, 1e-4, 2.5e-3, 0.9, 0.999, 1e-15, 1), iters)
+        algo = 24 * 3 * M * P + 32 * B * P      # parameter + two moments read and written, the views' 32-byte stage records read
+        out["sh_adam"] = entry(ms, algo, algo)
+        del st, prm, m1, m2
+    n_geo = 17 * P
+    flat = torch.randn(n_geo, device=dev)
+    grad = torch.randn(n_geo, device=dev)
+    m1, m2 = torch.zeros_like(flat), torch.zeros_like(flat)
+    seg = (_capi.FdgsAdamSegment * 1)(_capi.FdgsAdamSegment(0, n_geo, 1e-4, 1e-4, 0, 0))
+
+    def geo():
+        with torch.cuda.device(dev):
+            _capi._check(_capi.lib.fdgs_adam_step(flat.data_ptr(), grad.data_ptr(), m1.data_ptr(), m2.data_ptr(), n_geo, seg, 1,
+                                                  0.9, 0.999, 1e-15, 1, _capi.current_stream_handle(dev)), "fdgs_adam_step")
+    ms = timed(geo, iters)
+    out["geometry_adam"] = entry(ms, 28 * n_geo, 28 * n_geo)
+    del flat, grad, m1, m2
+    img = torch.rand(3, H, W, generator=g).to(dev)
+    gt = torch.rand(3, H, W, generator=g).to(dev)
+    up = torch.ones((), device=dev)
+    ms = timed(lambda: l1_ssim_grad(img, gt, 0.2, up), iters)
+    N = W * H
+    # forward: both images in, three derivative maps out; backward: the maps and both images in, the gradient out (3 channels, 4 bytes)
+    out["l1_ssim"] = entry(ms, (24 + 36 + 60 + 12) * N, (24 + 36 + 12) * N)
+    if workload in ("C3", "C5"):
+        # HBM bytes per launch from the committed counter passes of the same step (not this run): read + write, gfx950 corrections applied
+        for k, stage in (("sh_adam", "sh_flush"), ("geometry_adam", "adam")):
+            if k in out:
+                out[k]["traffic"] = pmc_traffic(stage, workload)
+        if "l1_ssim" in out:
+            f, b = pmc_traffic("ssim_fwd", workload), pmc_traffic("ssim_bwd", workload)
+            out["l1_ssim"]["traffic"] = None if f is None or b is None else f + b
+    best = max((k for k in out if out[k]["working_set_bytes"] > 256 << 20), key=lambda k: out[k]["frac_of_hbm_peak"], default=None)
+    if best is not None:
+        out["hbm_bound_best"] = {"stage": best, "frac_of_hbm_peak": out[best]["frac_of_hbm_peak"], "gbps": out[best]["gbps"], "ms": out[best]["ms"],
+                                 "algo_bytes": out[best]["algo_bytes"], "traffic": out[best].get("traffic")}
+    out["what"] = ("stand-alone HIP-event times of the step's stages outside the rasterizer (buffers of the workload's size): sh_adam = the fused SH flush + "
+                   "Adam over the SH coefficients (24 B per coefficient + 32 B per Gaussian and view), geometry_adam = 28 B per geometry float, "
+                   "l1_ssim = value partials + gradient (132 B per pixel); hbm_bound_best = the best of those whose working set exceeds the "
+                   "256 MB Infinity Cache")
+    return out
+
+
 def c5_leg(args, dev, make_cams, pipe, B):
     """BASELINE configs[4] (2 M Gaussians, 2704x2028, SH degree 3: "HBM-bound stress; rocprof GB/s vs roofline") through the same
     step as `value`: images/s on two streams, the per-stage table of a single-stream pass with every stage's algorithmic bytes and
@@ -510,6 +586,8 @@ def c5_leg(args, dev, make_cams, pipe, B):
            "what": "BASELINE configs[4] (C5: %d Gaussians, %dx%d, SH degree %d, M = %d) through the same two-stream step as `value`, %d views per step; "
                    "stages: one single-stream step, HIP events per stage" % (P, W, H, cfg.sh_degree, M, B)}
     del sp2, model, opt, snap
+    torch.cuda.empty_cache()
+    out["step_end_stages"] = step_end_stages(dev, P, M, B, W, H, cfg.sh_degree, cfg.sh_degree_t, cfg.gaussian_dim, cfg.force_sh_3d, iters=10, workload="C5")
     torch.cuda.empty_cache()
     return out
 
@@ -1232,6 +1310,10 @@ def main():
         if ref_gpu is not None:
             out["cpu_baseline"]["reference_kernels_on_this_gpu"] = ref_gpu
             out["reference_hipified_images_s"] = ref_gpu["images_s"]
+    if world == 1:
+        out["step_end_stages"] = step_end_stages(dev, P, M, B, W, H, cfg.sh_degree, cfg.sh_degree_t, cfg.gaussian_dim, cfg.force_sh_3d, workload=cfg.name)
+        if "hbm_bound_best" in out["step_end_stages"]:
+            out["hbm_bound_best"] = out["step_end_stages"]["hbm_bound_best"]
     print(json.dumps(front_loaded(out)))
 
 
@@ -1241,11 +1323,12 @@ def front_loaded(out):
     detail) follow under the same keys as before, the notes of `roofline` under `roofline_notes`."""
     first = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
              "value_median", "value_reference_lists", "value_axis_camera", "value_rig_camera", "forward_ms", "forward_mpix_s", "c5_images_s",
-             "clustered_images_s", "raster_images_s", "reference_hipified_images_s", "dropin_images_s", "random_order_images_s")
+             "clustered_images_s", "raster_images_s", "reference_hipified_images_s", "dropin_images_s", "random_order_images_s", "hbm_bound_best")
     head = {k: out[k] for k in first if k in out}
     if "c5" in out and isinstance(out["c5"], dict):
         c5r = out["c5"].get("roofline") or {}
         head["c5_summary"] = {"forward_ms": out["c5"].get("forward_ms"), "end_to_end_frac_of_hbm_peak": out["c5"].get("end_to_end_frac_of_hbm_peak"),
+                              "hbm_bound_best": (out["c5"].get("step_end_stages") or {}).get("hbm_bound_best"),
                               "roofline": {k: c5r.get(k) for k in ("kernel", "achieved", "peak", "frac", "traffic") if k in c5r}}
     if "roofline" in out:
         r = out["roofline"]
