@@ -587,7 +587,13 @@ def c5_leg(args, dev, make_cams, pipe, B):
                    "stages: one single-stream step, HIP events per stage" % (P, W, H, cfg.sh_degree, M, B)}
     del sp2, model, opt, snap
     torch.cuda.empty_cache()
-    out["step_end_stages"] = step_end_stages(dev, P, M, B, W, H, cfg.sh_degree, cfg.sh_degree_t, cfg.gaussian_dim, cfg.force_sh_3d, iters=10, workload="C5")
+    ses = step_end_stages(dev, P, M, B, W, H, cfg.sh_degree, cfg.sh_degree_t, cfg.gaussian_dim, cfg.force_sh_3d, iters=10, workload="C5")
+    out["step_end_stages"] = ses
+    # the wall time per view covers the loss and the optimizer step as well: their algorithmic bytes belong into the same sum (per view: the
+    # loss once, the two Adam launches of the step divided by its B views)
+    extra = ses.get("l1_ssim", {}).get("algo_bytes", 0) + (ses.get("sh_adam", {}).get("algo_bytes", 0) + ses.get("geometry_adam", {}).get("algo_bytes", 0)) / B
+    out["algo_bytes_per_view_with_loss_and_optimizer"] = int(total_bytes + extra)
+    out["end_to_end_frac_of_hbm_peak_with_loss_and_optimizer"] = round((total_bytes + extra) / (ms_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     torch.cuda.empty_cache()
     return out
 
@@ -1328,6 +1334,7 @@ def front_loaded(out):
     if "c5" in out and isinstance(out["c5"], dict):
         c5r = out["c5"].get("roofline") or {}
         head["c5_summary"] = {"forward_ms": out["c5"].get("forward_ms"), "end_to_end_frac_of_hbm_peak": out["c5"].get("end_to_end_frac_of_hbm_peak"),
+                              "end_to_end_frac_of_hbm_peak_with_loss_and_optimizer": out["c5"].get("end_to_end_frac_of_hbm_peak_with_loss_and_optimizer"),
                               "hbm_bound_best": (out["c5"].get("step_end_stages") or {}).get("hbm_bound_best"),
                               "roofline": {k: c5r.get(k) for k in ("kernel", "achieved", "peak", "frac", "traffic") if k in c5r}}
     if "roofline" in out:
