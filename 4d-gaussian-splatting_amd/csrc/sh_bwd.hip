@@ -23,6 +23,7 @@
 // Q3 the last time block overwrites dRGB/dt, Q4 view direction from the SHIFTED mean.  fdgs_scene.analytic_sh_grad
 // (opt-in) switches Q1-Q3 to the analytic gradient of the forward pass.
 #pragma clang fp contract(off)
+#include <algorithm>
 #include "fdgs_common.h"
 #include "fdgs_math.h"
 
@@ -664,8 +665,8 @@ namespace fdgs
 	// 128-byte line of the 576-byte rows up to three times.
 	// ------------------------------------------------------------------------------------------------
 	constexpr int SHF_GPW = 32;
-	constexpr int SHF_ACT = 144;                // floats of the three coefficient blocks that can be active
-	constexpr int SHF_STRIDE = SHF_ACT + 1;     // odd: lane-per-row accesses are conflict free
+	// LDS row stride of the flush tile: the active blocks' floats + 1 (odd: lane-per-row accesses are conflict free)
+	static inline int shf_tile_stride(int D, int D_t, bool sh3d) { return 48 * ((!sh3d && D > 2) ? 1 + std::min(std::max(D_t, 0), 2) : 1) + 1; }
 #ifndef FDGS_SHF_BATCH
 #define FDGS_SHF_BATCH 6
 #endif
@@ -690,7 +691,10 @@ namespace fdgs
 	template <int MODE>
 	__global__ void __launch_bounds__(WAVE) sh_flush_kernel(const ShFlushArgs a)
 	{
-		__shared__ float tile[SHF_GPW * SHF_STRIDE];
+		// the tile holds the coefficient blocks that can carry a gradient: 48 floats per active block and Gaussian, + 1 (odd stride); its
+		// size is the launch's dynamic LDS (one active block -- 3D SH, M = 16, or the first iterations of the degree ramp -- takes a
+		// third of the three-block tile: more waves per CU for the streaming phase)
+		extern __shared__ float tile[];
 		const int lane = threadIdx.x, g = lane & (SHF_GPW - 1), half = lane >> 5;
 		const int g0 = blockIdx.x * SHF_GPW;
 		const bool valid = g0 + g < a.P;
@@ -700,6 +704,7 @@ namespace fdgs
 		const int ncoef0 = min(16, (a.D + 1) * (a.D + 1));
 		const int nblocks = (!sh3d && a.D > 2) ? 1 + min(max(a.D_t, 0), 2) : 1;
 		const int act_floats = min(48 * nblocks, row_floats);   // row prefix that can carry a gradient
+		const int stride = 48 * nblocks + 1;                    // = shf_tile_stride() of the launcher
 
 		float3 acc[3][8];
 #pragma unroll
@@ -732,14 +737,17 @@ namespace fdgs
 		const unsigned long long vmask = __ballot(any);   // bit g (and g + 32)
 		if (any)
 		{
-			float* row = tile + g * SHF_STRIDE + 24 * half;
+			float* row = tile + g * stride + 24 * half;
 #pragma unroll
 			for (int b = 0; b < 3; b++)
+			{
+				if (b >= nblocks) break;
 #pragma unroll
 				for (int j = 0; j < 8; j++)
 				{
 					row[48 * b + 3 * j] = acc[b][j].x; row[48 * b + 3 * j + 1] = acc[b][j].y; row[48 * b + 3 * j + 2] = acc[b][j].z;
 				}
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 
@@ -775,7 +783,7 @@ namespace fdgs
 					if (og[i] < 0) continue;
 					const int e0 = 4 * oq[i];
 					const bool live = ((vmask >> og[i]) & 1ull) && e0 < act_floats;
-					const float* t = tile + og[i] * SHF_STRIDE + e0;
+					const float* t = tile + og[i] * stride + e0;
 					float ge[4] = { 0.f, 0.f, 0.f, 0.f };
 					if (live) { ge[0] = t[0]; ge[1] = t[1]; ge[2] = t[2]; ge[3] = t[3]; }
 					const size_t o = (size_t)(g0 + og[i]) * row_floats + e0;
@@ -820,8 +828,8 @@ namespace fdgs
 				{
 					const bool live = ((vmask >> cg) & 1ull) && pos < act_floats;
 					float* d = a.dL_dsh + (size_t)(g0 + cg) * row_floats + pos;
-					if (!a.accum) *d = live ? tile[cg * SHF_STRIDE + pos] : 0.f;
-					else if (live) *d += tile[cg * SHF_STRIDE + pos];
+					if (!a.accum) *d = live ? tile[cg * stride + pos] : 0.f;
+					else if (live) *d += tile[cg * stride + pos];
 				}
 				cg += dg; pos += dpos;
 				if (pos >= row_floats) { pos -= row_floats; cg++; }
@@ -849,7 +857,7 @@ namespace fdgs
 		ShFlushArgs a;
 		fill_flush_args(a, P, D, D_t, M, gaussian_dim, force_sh_3d, analytic, nviews, stages, dL_dsh);
 		a.accum = accumulate;
-		hipLaunchKernelGGL(sh_flush_kernel<0>, dim3(div_up(P, SHF_GPW)), dim3(WAVE), 0, stream, a);
+		hipLaunchKernelGGL(sh_flush_kernel<0>, dim3(div_up(P, SHF_GPW)), dim3(WAVE), (size_t)SHF_GPW * shf_tile_stride(D, D_t, a.sh3d != 0) * sizeof(float), stream, a);
 		return hipGetLastError();
 	}
 
@@ -865,7 +873,7 @@ namespace fdgs
 		ShFlushArgs a;
 		fill_flush_args(a, P, D, D_t, M, gaussian_dim, force_sh_3d, analytic, nviews, stages, dL_dsh);
 		a.p = params; a.m = exp_avg; a.v = exp_avg_sq; a.k = k;
-		hipLaunchKernelGGL(sh_flush_kernel<1>, dim3(div_up(P, SHF_GPW)), dim3(WAVE), 0, stream, a);
+		hipLaunchKernelGGL(sh_flush_kernel<1>, dim3(div_up(P, SHF_GPW)), dim3(WAVE), (size_t)SHF_GPW * shf_tile_stride(D, D_t, a.sh3d != 0) * sizeof(float), stream, a);
 		return hipGetLastError();
 	}
 }
