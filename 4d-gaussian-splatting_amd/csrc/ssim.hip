@@ -5,13 +5,13 @@
 // C1 = 0.01^2, C2 = 0.03^2, mean over all pixels and channels).  The reference runs it as five
 // grouped 11x11 convolutions forward plus their backward through the DL library; on ROCm that
 // is ~7.6 ms per 1352x1014 image, four times the whole rasterizer.  Here:
-//   forward : one pass.  A 32x32 output tile loads its 42x42 halo of both images into LDS as (x, y) pairs, does
-//             the separable window (horizontal, then vertical) for the five moments
-//             (x, y, x^2, y^2, xy), evaluates SSIM and the three partial derivatives
+//   forward : one pass.  A 32x32 output tile loads its 42x42 halo of both images into LDS as pairs (u, v) = (x + y, x - y), does
+//             the separable window (horizontal, then vertical) for FOUR moments (u, v, u^2, v^2: round 6 -- the window statistics SSIM
+//             needs follow from them, see the kernel; rounds 1-5: five, x, y, x^2, y^2, xy), evaluates SSIM and the three partial derivatives
 //             d ssim/d mu1, d ssim/d E[x^2], d ssim/d E[xy] per pixel (kept for the backward),
 //             and writes per-tile partial sums of |x-y| and ssim (summed by the host: deterministic).
 //             The kernel is VALU-issue bound (SQ counters), so it is written for instruction count: the
-//             moments travel as pairs (x,y) (x^2,y^2) + xy -> three packed-fp32 FMAs per tap instead of five;
+//             moments travel as pairs (u,v) (u^2,v^2) -> two packed-fp32 FMAs per tap (rounds 2-5: (x,y) (x^2,y^2) + xy: three; before: five);
 //             a thread produces 4 adjacent outputs of the horizontal pass (14 b128-loaded inputs instead of
 //             44 scalar reads) and 4 adjacent rows of the vertical pass (14 row reads per 4 outputs).  Round 4: 32x32 tile
 //             instead of 32x16 (halo 1.72 x instead of 2.13 x the tile, 1.31 instead of 1.63 rows of horizontal pass per
@@ -42,7 +42,6 @@ namespace fdgs
 	constexpr int SSTR = 46;             // input tile, in (x,y) pairs
 	constexpr int SSTR1 = 48;            // input tile of the backward's scalar map
 	constexpr int HSTR = 38;             // horizontally filtered moments, pair arrays
-	constexpr int HSTR1F = 48;           // horizontally filtered scalar moment of the forward
 	constexpr int HSTR1B = 36;           // ... of the backward (48 would cost its sixth workgroup per CU)
 	constexpr int STHREADS = 256;
 	typedef float v2f __attribute__((ext_vector_type(2)));
@@ -82,13 +81,17 @@ namespace fdgs
 		// every task of the horizontal pass has read its inputs (a barrier in between).  A workgroup then holds 34 KB instead of 49
 		// (32-row tile): four workgroups per CU instead of three.  (All three behind the barrier: 16 more VGPRs for nothing -- the
 		// results are larger than the inputs.)
-		constexpr int IN_BYTES = SHH * SSTR * 8, HM_BYTES = SHH * HSTR * 8, HX_BYTES = SHH * HSTR1F * 4;
-		constexpr int SH_BYTES = IN_BYTES > HM_BYTES + HX_BYTES ? IN_BYTES : HM_BYTES + HX_BYTES;
+		// Round 6: FOUR moment channels instead of five, all of them packed pairs.  With u = x + y, v = x - y the window statistics SSIM
+		// needs are E[u], E[v], E[u^2], E[v^2]:  mu1, mu2 = (E[u] +- E[v]) / 2,  E[x^2] + E[y^2] = (E[u^2] + E[v^2]) / 2,  E[xy] = (E[u^2] -
+		// E[v^2]) / 4 -- the scalar fifth channel x y (a plain FMA per tap next to two packed ones, and per pair of outputs four register moves
+		// the compiler needed to feed it to a packed multiply) is gone: 3 -> 2 instructions per tap, one LDS array less (28 instead of 34 KB:
+		// five workgroups per CU instead of four).  sigma_1^2 and sigma_2^2 only ever enter SSIM as their sum.
+		constexpr int IN_BYTES = SHH * SSTR * 8, HM_BYTES = SHH * HSTR * 8;
+		constexpr int SH_BYTES = IN_BYTES > HM_BYTES ? IN_BYTES : HM_BYTES;
 		__shared__ __attribute__((aligned(16))) char s_raw[HM_BYTES + SH_BYTES];
-		v2f (*h_m)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw);                                   // horizontally filtered (x, y)
-		v2f (*s_in)[SSTR] = reinterpret_cast<v2f (*)[SSTR]>(s_raw + HM_BYTES);                       // (x, y)
-		v2f (*h_s)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw + HM_BYTES);                        // (x^2, y^2): over the input tile
-		float (*h_x)[HSTR1F] = reinterpret_cast<float (*)[HSTR1F]>(s_raw + 2 * HM_BYTES);            // x y: over the input tile
+		v2f (*h_m)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw);                                   // horizontally filtered (u, v)
+		v2f (*s_in)[SSTR] = reinterpret_cast<v2f (*)[SSTR]>(s_raw + HM_BYTES);                       // (u, v) = (x + y, x - y)
+		v2f (*h_s)[HSTR] = reinterpret_cast<v2f (*)[HSTR]>(s_raw + HM_BYTES);                        // (u^2, v^2): over the input tile
 		__shared__ float red[2][STHREADS / WAVE];
 
 		const TileId tile = ssim_tile_of((W + STX - 1) / STX, (H + STY - 1) / STY, C);
@@ -116,7 +119,7 @@ namespace fdgs
 				const bool in = col_in && ly < SHH && (unsigned)gy < (unsigned)H;
 				const size_t o = in ? plane + (size_t)gy * W + gxh : plane;   // branch-free: outside lanes read a valid address
 				const float vx = img1[o], vy = img2[o];
-				p[t] = in ? v2f{ vx, vy } : v2f{ 0.0f, 0.0f };               // zero padding (F.conv2d padding = 5)
+				p[t] = in ? v2f{ vx + vy, vx - vy } : v2f{ 0.0f, 0.0f };     // (u, v); zero padding (F.conv2d padding = 5)
 			}
 #pragma unroll
 			for (int t = 0; t < TRIPS; t++)
@@ -124,7 +127,7 @@ namespace fdgs
 				const int ly = lyb + t * RPT;
 				if (tid < RPT * SW && ly < SHH) s_in[ly][hx] = p[t];
 				const bool own = col_own && (unsigned)(ly - SR) < (unsigned)STY;   // (outside the image: 0 - 0)
-				l1 += own ? fabsf(p[t].x - p[t].y) : 0.0f;
+				l1 += own ? fabsf(p[t].y) : 0.0f;                                  // |x - y|
 			}
 		}
 		__syncthreads();
@@ -133,7 +136,6 @@ namespace fdgs
 		// registers until every task has read its inputs
 		constexpr int HR = (SHH * (STX / 4) + STHREADS - 1) / STHREADS;
 		v2f as[HR][4];
-		float ax[HR][4];
 #pragma unroll
 		for (int r = 0; r < HR; r++)
 		{
@@ -142,19 +144,18 @@ namespace fdgs
 			{
 				const int ly = task >> 3, cx = (task & 7) * 4;
 				v2f p[16], sq[14];
-				float xy[14];
 				const v4f* src = reinterpret_cast<const v4f*>(&s_in[ly][cx]);
 #pragma unroll
 				for (int i = 0; i < 7; i++) { const v4f q = src[i]; p[2 * i] = v2f{ q.x, q.y }; p[2 * i + 1] = v2f{ q.z, q.w }; }
 #pragma unroll
-				for (int i = 0; i < 14; i++) { sq[i] = p[i] * p[i]; xy[i] = p[i].x * p[i].y; }
+				for (int i = 0; i < 14; i++) sq[i] = p[i] * p[i];
 				v2f am[4];
 #pragma unroll
 				for (int j = 0; j < 4; j++)
 				{
-					am[j] = GW[0] * p[j]; as[r][j] = GW[0] * sq[j]; ax[r][j] = GW[0] * xy[j];
+					am[j] = GW[0] * p[j]; as[r][j] = GW[0] * sq[j];
 #pragma unroll
-					for (int k = 1; k < 11; k++) { am[j] += GW[k] * p[j + k]; as[r][j] += GW[k] * sq[j + k]; ax[r][j] += GW[k] * xy[j + k]; }
+					for (int k = 1; k < 11; k++) { am[j] += GW[k] * p[j + k]; as[r][j] += GW[k] * sq[j + k]; }
 				}
 				v4f* dm = reinterpret_cast<v4f*>(&h_m[ly][cx]);   // (its own bytes: written at once)
 				dm[0] = v4f{ am[0].x, am[0].y, am[1].x, am[1].y }; dm[1] = v4f{ am[2].x, am[2].y, am[3].x, am[3].y };
@@ -171,7 +172,6 @@ namespace fdgs
 				const int ly = task >> 3, cx = (task & 7) * 4;
 				v4f* ds = reinterpret_cast<v4f*>(&h_s[ly][cx]);
 				ds[0] = v4f{ as[r][0].x, as[r][0].y, as[r][1].x, as[r][1].y }; ds[1] = v4f{ as[r][2].x, as[r][2].y, as[r][3].x, as[r][3].y };
-				*reinterpret_cast<v4f*>(&h_x[ly][cx]) = v4f{ ax[r][0], ax[r][1], ax[r][2], ax[r][3] };
 			}
 		}
 		__syncthreads();
@@ -179,26 +179,25 @@ namespace fdgs
 		// vertical pass: thread -> (column, SROWS adjacent rows)
 		const int lx = tid & (STX - 1), ly0 = (tid >> 5) * SROWS;
 		v2f vm[10 + SROWS], vs[10 + SROWS];
-		float vx[10 + SROWS];
 #pragma unroll
-		for (int r = 0; r < 10 + SROWS; r++) { vm[r] = h_m[ly0 + r][lx]; vs[r] = h_s[ly0 + r][lx]; vx[r] = h_x[ly0 + r][lx]; }
+		for (int r = 0; r < 10 + SROWS; r++) { vm[r] = h_m[ly0 + r][lx]; vs[r] = h_s[ly0 + r][lx]; }
 		float sv = 0.f;
 		const int gx = x0 + lx;
 #pragma unroll
 		for (int j = 0; j < SROWS; j++)
 		{
 			v2f mu = GW[0] * vm[j], e2 = GW[0] * vs[j];
-			float e12 = GW[0] * vx[j];
 #pragma unroll
-			for (int k = 1; k < 11; k++) { mu += GW[k] * vm[j + k]; e2 += GW[k] * vs[j + k]; e12 += GW[k] * vx[j + k]; }
+			for (int k = 1; k < 11; k++) { mu += GW[k] * vm[j + k]; e2 += GW[k] * vs[j + k]; }
 			const int gy = y0 + ly0 + j;
 			if (gx < W && gy < H)
 			{
-				const float mu1 = mu.x, mu2 = mu.y, e11 = e2.x, e22 = e2.y;
+				const float mu1 = 0.5f * (mu.x + mu.y), mu2 = 0.5f * (mu.x - mu.y);   // from E[u], E[v]
+				const float e_sum = 0.5f * (e2.x + e2.y), e12 = 0.25f * (e2.x - e2.y);   // E[x^2] + E[y^2], E[xy] from E[u^2], E[v^2]
 				const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 				const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-				const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
-				const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sg1 + sg2 + C2;
+				const float sg12 = e12 - mu12;
+				const float A = 2.f * mu12 + C1, B = 2.f * sg12 + C2, Cc = mu1_sq + mu2_sq + C1, D = (e_sum - (mu1_sq + mu2_sq)) + C2;
 				// 1 / Cc and 1 / D by v_rcp_f32 (1 ulp): three IEEE divisions were a seventh of the kernel's instructions
 				const float rC = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D);
 				const float inv = rC * rD;
