@@ -387,7 +387,12 @@ def warm_up(step_fn, dev, world=1, at_least=3, at_most=10):
     of the device and every forward in flight holds its binning buffer (C3-clustered: 570 MB, C5: 656 MB with sparse lists) -- that
     depth, hence the last device allocations (tens of ms each on a busy GPU: a leg of 6-10 steps that contained four of them read
     half its rate), is only reached after three or four steps.  Several ranks: a fixed number (a step holds collectives)."""
+    # Round 6: a leg REHEARSES its own trajectory -- `at_least` = the number of steps it will time, from the model state it will start
+    # from (the leg restores that state again afterwards): Adam on noise targets shrinks the scene step by step, the run-ahead buffer
+    # sizes follow it, and ONE device allocation inside a leg of 20 steps (25-33 ms next to a busy device: `reference_lists` read 1100
+    # instead of 1720 images/s in every third run of rounds 5 and 6, `ms_per_step_max` 26 ms) is a third of its reading.
     gc.collect()   # (the collector is off during the legs: bench.py main)
+    at_most = max(at_most, at_least + 6)
     for k in range(at_most):
         n0 = torch.cuda.memory_stats(dev)["num_device_alloc"]
         step_fn()
@@ -542,7 +547,7 @@ def c5_leg(args, dev, make_cams, pipe, B):
     dom = max((k for k in prof if k != "readback"), key=lambda k: prof[k][0])
     sp2 = new_pipeline(model, opt, overlap=not args.no_overlap, overlap_steps=not args.no_overlap_steps, **kw)
     restore()
-    warm_up(lambda: sp2.step(cams, gts, pipe, bg), dev)
+    warm_up(lambda: sp2.step(cams, gts, pipe, bg), dev, at_least=max(3, args.c5_steps))
     restore()
     _capi.profile_reset()
     _capi.profile_enable(True, stages=[dom], every=PROFILE_EVERY)
@@ -1008,7 +1013,8 @@ def main():
                           gather_max_views=0 if args.dense_sh_exchange else 32, tile_cull=False, lazy=not args.no_lazy, sparse_lists=False,
                           overlap_steps=not args.no_overlap_steps)
         restore()
-        warm_up(lambda: rp.step(cams, gts, pipe, bg), dev, world)
+        warm_up(lambda: rp.step(cams, gts, pipe, bg), dev, world, at_least=max(3, args.reflists_steps))
+        restore()
         torch.cuda.synchronize(dev)
         barrier(world)
         r_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reflists_steps)]
@@ -1022,10 +1028,12 @@ def main():
         dtr = max_over_ranks(time.perf_counter() - tr0, world, dev)
         r_ms = sorted(a.elapsed_time(b) for a, b in r_ev)
         reflists = {"images_s": round(world * B * args.reflists_steps / dtr, 2), "ms_per_step": round(dtr / args.reflists_steps * 1e3, 4),
-                    # (this leg reads 1100-1200 instead of 1650-1700 in about every third run of the full line -- a few steps of several times the
-                    # usual length, cause not found; the median step is the same either way)
+                    # (rounds 5-6: this leg read 1100-1200 instead of 1700 in about every third run -- ONE step of 25-33 ms: a device allocation
+                    # inside the leg, found in round 6: warm_up now rehearses the leg's whole trajectory)
                     "images_s_median_step": round(world * B / (r_ms[len(r_ms) // 2] * 1e-3), 2), "ms_per_step_max": round(r_ms[-1], 4),
                     "steps": args.reflists_steps, "num_rendered": int(round(sum(r["num_rendered"] for r in rres) / len(rres))),
+                    "lazy_steps_redone": rp.lazy_redone,
+                    "step_ms_sorted_tail": [round(x, 3) for x in r_ms[-3:]],
                     "what": "the same step with tile_cull = 0 and sparse_lists = 0: point_list / ranges / n_contrib are the reference's, bit for bit (tests/test_gpu_parity.py)"}
         del rp
 
@@ -1042,7 +1050,7 @@ def main():
             restore()
             train_host.spatial_sort(model, opt)
             models_touched()
-        warm_up(step, dev, world)
+        warm_up(step, dev, world, at_least=max(3, args.spatial_order_steps))
         torch.cuda.synchronize(dev)
         barrier(world)
         ts0 = time.perf_counter()
@@ -1073,7 +1081,7 @@ def main():
         which = "axis" if args.cameras == "rig" else "rig"
         ocams = make_cams(scene, which)
         restore()
-        warm_up(lambda: steppipe.step(ocams, gts, pipe, bg), dev, world)
+        warm_up(lambda: steppipe.step(ocams, gts, pipe, bg), dev, world, at_least=max(3, args.axis_steps))
         restore()
         torch.cuda.synchronize(dev)
         barrier(world)
@@ -1108,7 +1116,7 @@ def main():
                           sparse_lists=not args.no_sparse_lists, overlap_steps=not args.no_overlap_steps)
         # (on the on-axis camera whatever --cameras says: the box is placed to project onto 15 % of THAT image, and the leg's full-size parity test uses it)
         ccams = [train_host.SyntheticCamera(cs, dev, timestamp=(b + 0.5) / B * cs["time_duration"]) for b in range(B)]
-        warm_up(lambda: cp.step(ccams, gts, pipe, bg), dev)
+        warm_up(lambda: cp.step(ccams, gts, pipe, bg), dev, at_least=max(3, args.clustered_steps))
         cm.flat.data.copy_(csnap[0]); co.exp_avg.copy_(csnap[1]); co.exp_avg_sq.copy_(csnap[2]); co.step_count = 0
         models_touched()
         torch.cuda.synchronize(dev)
