@@ -12,9 +12,13 @@ mkdir -p build
 COMMON="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function"
 # TUs whose float results feed integers (radius / tile rect / depth key bits) or must track the
 # oracle's operation order are built with FP contraction off (no FMA fusion).
+# -fno-slp-vectorize on the per-Gaussian kernels (round 6): the vectorizer turns their scalar fp32 chains into packed operations on register
+# PAIRS, with one or two moves per packed operation to line the operands up -- preprocess_fwd 235 -> 173 VGPRs (its colour half 214 -> 153:
+# three waves per SIMD), preprocess_bwd 132 -> 97 (five waves), sh_bwd 222 -> 211 and 6 % fewer instructions; the same IEEE operations one at
+# a time, bit-identical results (the whole GPU suite); step +0.4 % at C3, +0.9 % at C5, forward-only -3 %.
 # ssim: the SLP vectorizer pairs the scalar third channel of the backward's windows into packed multiplies that each need four register
 # moves to line their operands up (595 -> 568 instructions per thread without it; the forward is packed by hand either way)
-declare -A EXTRA=( [preprocess_fwd]="-ffp-contract=off" [preprocess_bwd]="-ffp-contract=off" [sh_bwd]="-ffp-contract=off" [knn]="-ffp-contract=off" [ssim]="-fno-slp-vectorize" )
+declare -A EXTRA=( [preprocess_fwd]="-ffp-contract=off -fno-slp-vectorize" [preprocess_bwd]="-ffp-contract=off -fno-slp-vectorize" [sh_bwd]="-ffp-contract=off -fno-slp-vectorize" [knn]="-ffp-contract=off" [ssim]="-fno-slp-vectorize" )
 OBJS=()
 PIDS=()
 for src in preprocess_fwd tilebin radix_sort blend_fwd blend_bwd preprocess_bwd sh_bwd ssim adam densify knn capi; do

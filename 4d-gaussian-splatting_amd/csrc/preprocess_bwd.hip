@@ -397,10 +397,11 @@ namespace fdgs
 		if (a.dL_drot_r) reinterpret_cast<float4*>(a.dL_drot_r)[idx] = drot_r;
 	}
 
-	// Two builds of the same body: 132 VGPRs = three waves per SIMD, and -- for scenes of a million Gaussians and more -- held to 128
-	// VGPRs = four waves per SIMD at the price of three 8-byte spills.  Measured (round 5): C5 (2 M Gaussians) 151 -> 141 us, 4.2 TB/s
-	// algorithmic / 4.8 TB/s of counted traffic; C3 (300 k Gaussians, 1172 workgroups: launch and tail, not occupancy) 34.3 -> 34.4 us
-	// and the two-stream step 0.3 % slower, so small scenes keep the first one.
+	// Two builds of the same body (round 5): 132 VGPRs = three waves per SIMD, and -- for scenes of a million Gaussians and more -- held
+	// to 128 VGPRs = four waves per SIMD at the price of three 8-byte spills (C5: 151 -> 141 us; C3 unchanged).  Round 6: the translation
+	// unit is built WITHOUT the SLP vectorizer (build.sh) -- its packed fp32 operations (725 of them here) need register PAIRS and 523
+	// moves to line operands up: 2524 -> 2642 instructions but 132 -> 97 VGPRs, no spills, five waves per SIMD for both builds (C5:
+	// 141 -> 131 us; the same IEEE operations one at a time: bit-identical results).
 	__global__ void __launch_bounds__(256) preprocess_bwd_kernel(const BwdArgs a) { preprocess_bwd_body(a); }
 	__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_bwd_kernel_w4(const BwdArgs a) { preprocess_bwd_body(a); }
 

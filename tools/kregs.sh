@@ -5,7 +5,7 @@ SRC=$1; shift || true
 CS=$(cd "$(dirname "$0")/../4d-gaussian-splatting_amd/csrc" && pwd)
 TMP=$(mktemp -d)
 EXTRA=""
-case $SRC in preprocess_fwd|preprocess_bwd|sh_bwd|knn) EXTRA="-ffp-contract=off";; ssim) EXTRA="-fno-slp-vectorize";; esac
+case $SRC in preprocess_fwd|preprocess_bwd|sh_bwd) EXTRA="-ffp-contract=off -fno-slp-vectorize";; knn) EXTRA="-ffp-contract=off";; ssim) EXTRA="-fno-slp-vectorize";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $EXTRA "$@" -S --cuda-device-only -o $TMP/k.s $CS/$SRC.hip
 python3 - $TMP/k.s <<'PY'
 import re, sys
