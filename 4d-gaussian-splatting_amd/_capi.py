@@ -24,7 +24,7 @@ FDGS_BUF_GEOMETRY, FDGS_BUF_BINNING, FDGS_BUF_IMAGE = 0, 1, 2
 _fp = C.c_void_p  # all device pointers travel as void*
 
 
-FDGS_VERSION = 503  # include/fdgs.h; checked against fdgs_version() at import
+FDGS_VERSION = 502  # include/fdgs.h; checked against fdgs_version() at import
 
 
 class _Sized(C.Structure):
@@ -53,13 +53,13 @@ class FdgsScene(_Sized):
 class FdgsForwardOut(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("out_color", _fp), ("out_flow", _fp), ("out_depth", _fp), ("out_T", _fp), ("radii", _fp),
                 ("out_means3D", _fp), ("covs_com", _fp), ("preprocessed", C.c_int32), ("split_colour", C.c_int32), ("tile_cull", C.c_int32),
-                ("lazy", C.c_int32), ("sparse_lists", C.c_int32), ("colour_stream", C.c_void_p), ("sh_jacobian", C.c_int32)]
+                ("lazy", C.c_int32), ("sparse_lists", C.c_int32), ("colour_stream", C.c_void_p)]
 
 
 class FdgsBackwardIn(_Sized):
     _fields_ = [("struct_size", C.c_uint32), ("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_alpha", _fp), ("dL_dout_flow", _fp),
                 ("radii", _fp), ("out_means3D", _fp), ("geom_buffer", _fp), ("binning_buffer", _fp),
-                ("image_buffer", _fp), ("num_rendered", C.c_int32), ("sh_jacobian", C.c_int32)]
+                ("image_buffer", _fp), ("num_rendered", C.c_int32)]
 
 
 class FdgsGeometryAdam(_Sized):

@@ -24,7 +24,7 @@ PIDS=()
 for src in preprocess_fwd tilebin radix_sort blend_fwd blend_bwd preprocess_bwd sh_bwd ssim adam densify knn capi; do
   obj=build/$src.o
   OBJS+=("$obj")
-  if [[ ! -f $obj || $src.hip -nt $obj || fdgs_common.h -nt $obj || blend_common.h -nt $obj || fdgs_math.h -nt $obj || sh_tables.h -nt $obj || ../../include/fdgs.h -nt $obj ]]; then
+  if [[ ! -f $obj || $src.hip -nt $obj || fdgs_common.h -nt $obj || blend_common.h -nt $obj || fdgs_math.h -nt $obj || ../../include/fdgs.h -nt $obj ]]; then
     $HIPCC $COMMON ${EXTRA[$src]:-} ${FDGS_EXTRA_FLAGS:-} -c $src.hip -o $obj &
     PIDS+=($!)
   fi

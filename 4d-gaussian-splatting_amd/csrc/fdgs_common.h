@@ -56,7 +56,6 @@ namespace fdgs
 	struct GeomLayout
 	{
 		size_t records, depths, cov3D, tiles_touched, rect, clamped;
-		size_t jac;   // [P][4] float4: d colour / d (direction, time) + the two time factors (fdgs_forward_out.sh_jacobian; see preprocess_fwd.hip)
 		size_t total;
 	};
 	static inline GeomLayout geom_layout(int P)
@@ -70,7 +69,6 @@ namespace fdgs
 		L.tiles_touched = o; o = align_up(o + p * 4);
 		L.rect = o; o = align_up(o + p * 8);
 		L.clamped = o; o = align_up(o + p);
-		L.jac = o; o = align_up(o + p * 64);
 		L.total = o;
 		return L;
 	}

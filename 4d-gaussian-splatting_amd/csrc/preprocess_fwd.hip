@@ -24,7 +24,6 @@
 #pragma clang fp contract(off)
 #include "fdgs_common.h"
 #include "fdgs_math.h"
-#include "sh_tables.h"
 
 namespace fdgs
 {
@@ -41,7 +40,6 @@ namespace fdgs
 		int32_t* radii; float* out_means3D; float* covs_com;
 		float4* records; float* depths; float* cov3D; uint32_t* tiles_touched; ushort4* rect; uint8_t* clamped;
 		uint32_t* bin_counters; int bin_counter_words;   // tile instance counters of the binning passes, cleared here (tilebin.hip)
-		float4* jac; int analytic;   // fdgs_forward_out.sh_jacobian: [P][4] (JAC instances of the kernel); fdgs_scene.analytic_sh_grad
 	};
 
 	__device__ __forceinline__ float3 ld3(const float* p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -381,14 +379,9 @@ namespace fdgs
 #ifdef FDGS_PRE_WAVES   // A/B: hold the kernel to 512 / FDGS_PRE_WAVES registers (3: 168 VGPRs and 66 spills; default: 235 VGPRs, two waves per SIMD)
 #define FDGS_PRE_OCC __attribute__((amdgpu_waves_per_eu(FDGS_PRE_WAVES, FDGS_PRE_WAVES)))
 #else
-#define FDGS_PRE_OCC __attribute__((amdgpu_waves_per_eu(2)))   // at least two waves per SIMD: the sh_jacobian instances would take 278 VGPRs otherwise
+#define FDGS_PRE_OCC
 #endif
-	// JAC (fdgs_forward_out.sh_jacobian): while a Gaussian's coefficient blocks pass through the LDS tile for its colour, the kernel also
-	// takes the sums the SH BACKWARD needs from the same rows -- d colour / d direction (3 x 3) and d colour / d time (3), evaluated at the
-	// backward's direction (Q4: from the SHIFTED mean) by the backward's own loop (sh_bwd.hip, backward.cu:172-481), operation by
-	// operation -- and stores them with the two time factors as 64 bytes per visible Gaussian.  The backward then never reads a
-	// coefficient row (sh_bwd_jac_kernel: 12 M + 76 bytes per live Gaussian -> 100): the rows travel once per view, not twice.
-	template <int PART, bool JAC>
+	template <int PART>
 	__global__ void __launch_bounds__(256) FDGS_PRE_OCC preprocess_fwd_kernel(const PreArgs a)
 	{
 		// every lane stays until the end: the SH blocks are staged cooperatively per wave
@@ -460,24 +453,9 @@ namespace fdgs
 			const float len = sqrtf(dot3(dir.x, dir.y, dir.z, dir.x, dir.y, dir.z));
 			dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
 			float l[16];
-			if constexpr (!JAC) { if (!sh3d) sh_basis_4d(a.D, dir.x, dir.y, dir.z, l); }
+			if (!sh3d) sh_basis_4d(a.D, dir.x, dir.y, dir.z, l);
 			const float dir_t = (!sh3d) ? a.ts[idx] - a.timestamp : 0.f;
 			float3 c = make_float3(0.f, 0.f, 0.f);
-			// JAC: the backward's tables at the backward's direction, its sums (sh_bwd.hip: gx, gy, gz, gt) and time factors
-			// (the JAC instance builds its tables -- the forward's l[] as well -- INSIDE the block loop from direction components the
-			// compiler cannot see through: 60 table registers live across the staging of a block, next to its 48 staging registers, put
-			// the kernel at 320 VGPRs = one wave per SIMD; rebuilt per block they only live through the evaluation)
-			float3 jgx = make_float3(0.f, 0.f, 0.f), jgy = jgx, jgz = jgx, jgt = jgx;
-			float jtk[2] = { 0.f, 0.f };
-			float3 dirb = dir;
-			if constexpr (JAC)
-			{
-				float3 p_b = p_orig;   // the shifted mean (PART 2: as the geometry launch stored it)
-				if constexpr (PART == 2) p_b = ld3(a.out_means3D, idx);
-				const float3 dob = sub3(p_b, make_float3(a.campos[0], a.campos[1], a.campos[2]));
-				const float lenb = sqrtf(dob.x * dob.x + dob.y * dob.y + dob.z * dob.z);
-				dirb = make_float3(dob.x / lenb, dob.y / lenb, dob.z / lenb);
-			}
 			for (int blk = 0; blk < nblocks; blk++)
 			{
 				stage_sh_block(tile, a.shs, g0, a.P, a.M, 16 * blk, blk == 0 ? ncoef0 : 16, amask, lane, a.sh_vec_ok != 0);
@@ -486,12 +464,6 @@ namespace fdgs
 				FDGS_TILE_SYNC();
 				if (alive)
 				{
-					if constexpr (JAC)
-					{
-						float x = dir.x, y = dir.y, z = dir.z;
-						asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-						if (!sh3d) sh_basis_4d(a.D, x, y, z, l);
-					}
 					if (blk == 0) c = sh3d ? sh_color_3d(a.D, row, dir) : sh4d_block0(a.D, l, row);
 					else
 					{
@@ -499,61 +471,8 @@ namespace fdgs
 						                            : (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
 						c = add3(c, scl3(tk, sh_weighted(l, row, 0, 15, 0)));
 					}
-					if constexpr (JAC)
-					{
-						// sh_bwd_kernel's block loop (sh_bwd.hip), verbatim but for what needs dL_dRGB
-						float jl[16], jdX[16], jdY[16], jdZ[16];
-						{
-							float x = dirb.x, y = dirb.y, z = dirb.z;
-							asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-							sh_tables(a.D, x, y, z, !sh3d, jl, jdX, jdY, jdZ);
-						}
-						const int nk = (blk == 0) ? ncoef0 : 16;
-						float tk = 1.f, dtk_dt = 0.f;
-						if (blk == 1)
-						{
-							tk = (float)cos(2 * REF_PI * dir_t / a.time_duration);
-							dtk_dt = (float)(sin(2 * REF_PI * dir_t / a.time_duration) * 2 * REF_PI / a.time_duration); // Q2
-						}
-						else if (blk == 2)
-						{
-							tk = (float)cos(2 * REF_PI * dir_t * 2 / a.time_duration);
-							dtk_dt = (float)(sin(2 * REF_PI * dir_t * 2 / a.time_duration) * 2 * REF_PI * 2 / a.time_duration);
-						}
-						if (a.analytic) dtk_dt = -dtk_dt;
-						if (blk == 1) jtk[0] = tk;
-						if (blk == 2) jtk[1] = tk;
-						float3 st = make_float3(0.f, 0.f, 0.f), sx = st, sy = st, sz = st;
-#pragma unroll
-						for (int k = 0; k < 16; k++)
-						{
-							if (k >= nk) break;
-							const float3 s = ld3(row, k);
-							st = add3(st, scl3(jl[k], s));
-							sx = add3(sx, scl3(jdX[k], s));
-							sy = add3(sy, scl3(jdY[k], s));
-							sz = add3(sz, scl3(jdZ[k], s));
-						}
-						if (blk == 0) { jgx = sx; jgy = sy; jgz = sz; }
-						else
-						{
-							jgx = add3(jgx, scl3(tk, sx)); jgy = add3(jgy, scl3(tk, sy)); jgz = add3(jgz, scl3(tk, sz));
-							jgt = a.analytic ? add3(jgt, scl3(dtk_dt, st)) : scl3(dtk_dt, st); // Q3
-						}
-					}
 				}
 				FDGS_TILE_SYNC();
-			}
-			if constexpr (JAC)
-			{
-				if (alive && valid)
-				{
-					float4* j = a.jac + 4 * (size_t)idx;
-					j[0] = make_float4(jgx.x, jgx.y, jgx.z, jtk[0]);
-					j[1] = make_float4(jgy.x, jgy.y, jgy.z, jtk[1]);
-					j[2] = make_float4(jgz.x, jgz.y, jgz.z, 0.f);
-					j[3] = make_float4(jgt.x, jgt.y, jgt.z, 0.f);
-				}
 			}
 			if (alive)
 			{
@@ -628,15 +547,9 @@ namespace fdgs
 		a.clamped = reinterpret_cast<uint8_t*>(geom + L.clamped);
 		a.bin_counters = bin_counters;
 		a.bin_counter_words = (int)bin_counter_words(a.grid_x * a.grid_y);
-		a.analytic = s.analytic_sh_grad;
-		const bool jac = out.sh_jacobian != 0 && s.shs != nullptr && s.colors_precomp == nullptr && part != 1;
-		a.jac = jac ? reinterpret_cast<float4*>(geom + L.jac) : nullptr;
-		const dim3 grid(div_up(s.P, 256)), block(256);
-		if (part == 1) hipLaunchKernelGGL((preprocess_fwd_kernel<1, false>), grid, block, 0, stream, a);
-		else if (part == 2 && jac) hipLaunchKernelGGL((preprocess_fwd_kernel<2, true>), grid, block, 0, stream, a);
-		else if (part == 2) hipLaunchKernelGGL((preprocess_fwd_kernel<2, false>), grid, block, 0, stream, a);
-		else if (jac) hipLaunchKernelGGL((preprocess_fwd_kernel<0, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((preprocess_fwd_kernel<0, false>), grid, block, 0, stream, a);
+		if (part == 1) hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		else if (part == 2) hipLaunchKernelGGL(preprocess_fwd_kernel<2>, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(preprocess_fwd_kernel<0>, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a);
 		return hipGetLastError();
 	}
 

@@ -26,7 +26,6 @@
 #include <algorithm>
 #include "fdgs_common.h"
 #include "fdgs_math.h"
-#include "sh_tables.h"
 
 namespace fdgs
 {
@@ -49,6 +48,48 @@ namespace fdgs
 	__device__ __forceinline__ float3 s_add(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
 	__device__ __forceinline__ float3 s_scl(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
 	__device__ __forceinline__ float s_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+	// basis values and derivatives (backward.cu:172-263); entries the reference has no term for stay zero
+	__device__ __forceinline__ void sh_tables(int deg, float x, float y, float z, bool promote, float* l, float* dX, float* dY, float* dZ)
+	{
+#pragma unroll
+		for (int k = 0; k < 16; k++) { l[k] = 0.f; dX[k] = 0.f; dY[k] = 0.f; dZ[k] = 0.f; }
+		l[0] = SH_C0;
+		if (deg > 0)
+		{
+			l[1] = -1 * SH_C1 * y; l[2] = SH_C1 * z; l[3] = -1 * SH_C1 * x;
+			dY[1] = -1 * SH_C1; dZ[2] = SH_C1; dX[3] = -1 * SH_C1;
+			if (deg > 1)
+			{
+				const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+				l[4] = SH_C2[0] * xy; l[5] = SH_C2[1] * yz;
+				l[6] = promote ? (float)(SH_C2[2] * (2.0 * zz - xx - yy)) : SH_C2[2] * (2.f * zz - xx - yy);
+				l[7] = SH_C2[3] * xz; l[8] = SH_C2[4] * (xx - yy);
+				dX[4] = SH_C2[0] * y; dY[4] = SH_C2[0] * x;
+				dY[5] = SH_C2[1] * z; dZ[5] = SH_C2[1] * y;
+				dX[6] = -2 * SH_C2[2] * x; dY[6] = -2 * SH_C2[2] * y; dZ[6] = 4 * SH_C2[2] * z;
+				dX[7] = SH_C2[3] * z; dZ[7] = SH_C2[3] * x;
+				dX[8] = 2 * SH_C2[4] * x; dY[8] = -2 * SH_C2[4] * y;
+				if (deg > 2)
+				{
+					l[9] = SH_C3[0] * y * (3 * xx - yy);
+					l[10] = SH_C3[1] * xy * z;
+					l[11] = SH_C3[2] * y * (4 * zz - xx - yy);
+					l[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+					l[13] = SH_C3[4] * x * (4 * zz - xx - yy);
+					l[14] = SH_C3[5] * z * (xx - yy);
+					l[15] = SH_C3[6] * x * (xx - 3 * yy);
+					dX[9] = SH_C3[0] * y * 6 * x;               dY[9] = SH_C3[0] * (3 * xx - 3 * yy);
+					dX[10] = SH_C3[1] * yz;                     dY[10] = SH_C3[1] * xz;                     dZ[10] = SH_C3[1] * xy;
+					dX[11] = -SH_C3[2] * y * 2 * x;             dY[11] = SH_C3[2] * (4 * zz - xx - 3 * yy);  dZ[11] = SH_C3[2] * y * 8 * z;
+					dX[12] = -SH_C3[3] * z * 6 * x;             dY[12] = -SH_C3[3] * z * 6 * y;             dZ[12] = SH_C3[3] * (6 * zz - 3 * xx - 3 * yy);
+					dX[13] = SH_C3[4] * (4 * zz - 3 * xx - yy);  dY[13] = -SH_C3[4] * x * 2 * y;             dZ[13] = SH_C3[4] * x * 8 * z;
+					dX[14] = SH_C3[5] * z * 2 * x;              dY[14] = -SH_C3[5] * z * 2 * y;             dZ[14] = SH_C3[5] * (xx - yy);
+					dX[15] = SH_C3[6] * (3 * xx - 3 * yy);      dY[15] = -SH_C3[6] * x * 6 * y;
+				}
+			}
+		}
+	}
 
 	// ---- tile <-> global, coalesced; tile row r belongs to Gaussian g0 + list[r], r < nrows ----
 	constexpr int SHB_BATCH = 6;     // float4 per lane in flight while staging (2 batches per block)
@@ -335,46 +376,6 @@ namespace fdgs
 		}
 	}
 
-	// The deferred SH backward of a view whose FORWARD kept the coefficient sums (fdgs_forward_out.sh_jacobian, preprocess_fwd.hip:
-	// gx, gy, gz, gt of sh_bwd_kernel above, taken while the rows were on the chip for the colour): what is left is linear in the
-	// Gaussian's dL_dRGB and needs no coefficient -- one lane per Gaussian, 21 bytes in for every one, 64 + 12 more and 48 out for a
-	// live one.  Same operations in the same order as the tail of sh_bwd_kernel<true>: the stage record and record words 12..15 are
-	// the same bit for bit.
-	__global__ void __launch_bounds__(256) sh_bwd_jac_kernel(const ShBwdArgs a, const float4* __restrict__ jac)
-	{
-		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-		if (idx >= a.P) return;
-		bool live = false;
-		float3 dRGB = make_float3(0.f, 0.f, 0.f);
-		if (a.radii[idx] > 0)
-		{
-			dRGB = colour_gradient(a, idx);
-			live = dRGB.x != 0.f || dRGB.y != 0.f || dRGB.z != 0.f;
-		}
-		if (!live) { a.stage[2 * (size_t)idx] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-		const bool sh3d = (a.gaussian_dim == 3 || a.force_sh_3d);
-		const float4 j0 = jac[4 * (size_t)idx], j1 = jac[4 * (size_t)idx + 1], j2 = jac[4 * (size_t)idx + 2], j3 = jac[4 * (size_t)idx + 3];
-		const float3 mean = make_float3(a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
-		const float3 dir_orig = make_float3(mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]); // Q4: shifted mean
-		const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-		const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-		const float3 gx = make_float3(j0.x, j0.y, j0.z), gy = make_float3(j1.x, j1.y, j1.z), gz = make_float3(j2.x, j2.y, j2.z),
-		             gt = make_float3(j3.x, j3.y, j3.z);
-		a.stage[2 * (size_t)idx] = make_float4(dRGB.x, dRGB.y, dRGB.z, j0.w);
-		a.stage[2 * (size_t)idx + 1] = make_float4(dir.x, dir.y, dir.z, j1.w);
-		float4 o;
-		const float3 ddir = make_float3(s_dot(gx, dRGB), s_dot(gy, dRGB), s_dot(gz, dRGB));
-		// dnormvdv, auxiliary.h:108-118
-		const float3 v = dir_orig;
-		const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-		o.x = ((+sum2 - v.x * v.x) * ddir.x - v.y * v.x * ddir.y - v.z * v.x * ddir.z) * invsum32;
-		o.y = (-v.x * v.y * ddir.x + (sum2 - v.y * v.y) * ddir.y - v.z * v.y * ddir.z) * invsum32;
-		o.z = (-v.x * v.z * ddir.x - v.y * v.z * ddir.y + (sum2 - v.z * v.z) * ddir.z) * invsum32;
-		o.w = sh3d ? 0.f : s_dot(gt, dRGB);
-		reinterpret_cast<float4*>(a.gacc + (size_t)idx * GRAD_ACC_WORDS)[3] = o;
-	}
-
 	// wave slots of the device for a one-wave kernel (occupancy x CUs), per device
 	template <typename K>
 	static int resident_waves(K kernel)
@@ -401,12 +402,6 @@ namespace fdgs
 		a.clamped = reinterpret_cast<const uint8_t*>(geom + L.clamped);
 		a.gacc = out.grad_accum; a.dL_dsh = out.dL_dsh; a.accum = out.accumulate;
 		a.stage = reinterpret_cast<float4*>(out.sh_stage);
-		if (in.sh_jacobian != 0 && out.sh_stage != nullptr)
-		{
-			// the forward kept the coefficient sums: no row is read (fdgs_backward_in.sh_jacobian)
-			hipLaunchKernelGGL(sh_bwd_jac_kernel, dim3(div_up(s.P, 256)), dim3(256), 0, stream, a, reinterpret_cast<const float4*>(geom + L.jac));
-			return hipGetLastError();
-		}
 		// one wave per wave slot the device has for this kernel (cached per device)
 		constexpr int MAXDEV = 64;
 		static int slots_of[2][MAXDEV] = {};   // same value whoever writes it first

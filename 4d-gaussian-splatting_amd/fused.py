@@ -31,14 +31,13 @@ def _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_r
 
 
 def raw_forward(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
-                split_colour=False, preprocessed=None, tile_cull=False, lazy=False, sparse_lists=False, colour_stream=None, sh_jacobian=False):
+                split_colour=False, preprocessed=None, tile_cull=False, lazy=False, sparse_lists=False, colour_stream=None):
     """Native forward on RAW parameters (fdgs_scene.raw_params = 1); the reference binding's 11-tuple.
     ``preprocessed``: the view's handle from ``raw_preprocess_batch``; ``tile_cull``: fdgs_forward_out.tile_cull; ``lazy``:
-    fdgs_forward_out.lazy (num_rendered comes back as -1, the host does not wait); ``sparse_lists``: fdgs_forward_out.sparse_lists; ``colour_stream``: fdgs_forward_out.colour_stream (a torch.cuda.Stream);
-    ``sh_jacobian``: fdgs_forward_out.sh_jacobian (pass the same to ``raw_backward``)."""
+    fdgs_forward_out.lazy (num_rendered comes back as -1, the host does not wait); ``sparse_lists``: fdgs_forward_out.sparse_lists; ``colour_stream``: fdgs_forward_out.colour_stream (a torch.cuda.Stream)."""
     args = _raw_forward_args(rs, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var)
     return _C.rasterize_gaussians(*args, raw_params=True, split_colour=split_colour, preprocessed=preprocessed, tile_cull=tile_cull, lazy=lazy,
-                                  sparse_lists=sparse_lists, colour_stream=colour_stream, sh_jacobian=sh_jacobian)
+                                  sparse_lists=sparse_lists, colour_stream=colour_stream)
 
 
 def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw, prefilter_var,
@@ -52,7 +51,7 @@ def raw_preprocess_batch(settings, means3D, sh, opacity_raw, ts, scaling_raw, sc
 
 def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_raw, scaling_t_raw, rotation_raw, rotation_r_raw,
                  prefilter_var, geom, R, binb, img, g_color, g_depth, g_alpha, g_flow, sink, accumulate, grad_accum=None, after_sh=None,
-                 sh_stage=None, begin_only=False, per_view_outputs=True, geometry_adam=None, sh_jacobian=False):
+                 sh_stage=None, begin_only=False, per_view_outputs=True, geometry_adam=None):
     """Native backward on RAW parameters; gradients go into ``sink`` where given; the binding's 12-tuple.
     ``begin_only``: only the blend backward (``_C.backward_begin``): returns the pending call for ``_C.sh_backward_batch`` /
     ``_C.backward_finish``.  ``per_view_outputs=False``: dL_dcolors / dL_dcov3D / dL_dflows are not written (None in the tuple).
@@ -66,8 +65,7 @@ def raw_backward(rs, means3D, out_means3D, radii, sh, opacity_raw, ts, scaling_r
         return _C.backward_begin(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum, sh_stage=sh_stage,
                                  per_view_outputs=per_view_outputs)
     return _C.rasterize_gaussians_backward(*args, raw_params=True, grad_out=sink, accumulate=accumulate, grad_accum=grad_accum,
-                                           after_sh=after_sh, sh_stage=sh_stage, per_view_outputs=per_view_outputs, geometry_adam=geometry_adam,
-                                           sh_jacobian=sh_jacobian)
+                                           after_sh=after_sh, sh_stage=sh_stage, per_view_outputs=per_view_outputs, geometry_adam=geometry_adam)
 
 
 def raw_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0):

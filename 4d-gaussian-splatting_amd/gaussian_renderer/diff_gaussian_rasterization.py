@@ -118,7 +118,7 @@ class _NativeRasterizer:
                             scale_modifier, cov3D_precomp, prefilter_var, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, degree_t, campos, timestamp, time_duration, rot_4d,
                             gaussian_dim, force_sh_3d, prefiltered, debug, *, raw_params=False, split_colour=False, preprocessed=None,
-                            tile_cull=False, lazy=False, sparse_lists=False, colour_stream=None, sh_jacobian=False):
+                            tile_cull=False, lazy=False, sparse_lists=False, colour_stream=None):
         """30 positional arguments and the 11-tuple result of the reference binding (rasterize_points.h:18-49).
         Keyword-only extensions: ``raw_params``: the scale / opacity / rotation tensors are the model's raw
         parameters and the kernels apply the activations (fdgs_scene.raw_params); ``split_colour``: the SH colour evaluation
@@ -128,8 +128,7 @@ class _NativeRasterizer:
         (returned as -1; the backward takes it) and ``_capi.forward_lazy_status`` later says whether the run-ahead buffers fitted;
         ``sparse_lists`` (with ``lazy``): fdgs_forward_out.sparse_lists -- every tile's list at a fixed offset of the binning buffer, no
         count / scan launches; ``colour_stream`` (with ``split_colour``): the torch.cuda.Stream the colour launch goes onto instead of
-        the library's own (fdgs_forward_out.colour_stream); ``sh_jacobian``: fdgs_forward_out.sh_jacobian -- a training forward whose
-        backward (``sh_stage`` given, ``sh_jacobian=True`` there too) then reads no SH coefficient (ignored with ``preprocessed``)."""
+        the library's own (fdgs_forward_out.colour_stream)."""
         if not means3D.is_cuda:
             raise RuntimeError("fdgs: means3D must live on the GPU; there is no CPU path")
         dev = means3D.device
@@ -160,8 +159,7 @@ class _NativeRasterizer:
                                    _capi._ptr(radii), _capi._ptr(out_means3D), _capi._ptr(covs_com),
                                    int(preprocessed is not None), int(bool(split_colour)),
                                    int(preprocessed["tile_cull"] if preprocessed is not None else bool(tile_cull)), int(bool(lazy)),
-                                   int(bool(sparse_lists)), colour_stream.cuda_stream if colour_stream is not None else None,
-                                   int(bool(sh_jacobian) and preprocessed is None))
+                                   int(bool(sparse_lists)), colour_stream.cuda_stream if colour_stream is not None else None)
         R = C.c_int32(0)
         with torch.cuda.device(dev):
             rc = _capi.lib.fdgs_rasterize_forward(C.byref(scene), C.byref(out), scratch.callback, None,
@@ -189,7 +187,7 @@ class _NativeRasterizer:
                  "tile_cull": bool(tile_cull)}
             h["scratch"].reuse = True
             h["out"] = _capi.FdgsForwardOut(None, None, None, None, _capi._ptr(h["radii"]), _capi._ptr(h["out_means3D"]),
-                                            _capi._ptr(h["covs_com"]), 0, 0, int(bool(tile_cull)), 0, 0, None, 0)
+                                            _capi._ptr(h["covs_com"]), 0, 0, int(bool(tile_cull)), 0, 0, None)
             handles.append(h)
         B = len(handles)
         scenes = (C.POINTER(_capi.FdgsScene) * B)(*[C.pointer(h["scene"]) for h in handles])
@@ -240,8 +238,7 @@ class _NativeRasterizer:
                                      dL_dout_mask, dL_dout_flow, sh, degree, degree_t, campos, timestamp,
                                      time_duration, rot_4d, gaussian_dim, force_sh_3d, geomBuffer, R, binningBuffer,
                                      imageBuffer, debug, *, raw_params=False, grad_out=None, accumulate=False, grad_accum=None,
-                                     after_sh=None, sh_stage=None, per_view_outputs=True, geometry_adam=None, sh_jacobian=False,
-                                     _phase=None):
+                                     after_sh=None, sh_stage=None, per_view_outputs=True, geometry_adam=None, _phase=None):
         """37 positional arguments and the 12-tuple result of the reference binding (rasterize_points.h:51-89).
         Keyword-only extensions: ``raw_params`` as in the forward; ``grad_out`` maps gradient names
         (dL_dmeans3D, dL_dsh, dL_dopacity, dL_dts, dL_dscales, dL_dscales_t, dL_drotations, dL_drotations_r) to
@@ -256,8 +253,7 @@ class _NativeRasterizer:
         ``per_view_outputs=False``: dL_dcolors, dL_dcov3D and dL_dflows are not written (NULL at the C ABI) and come back as None;
         ``geometry_adam``: a callable evaluated right before the geometry backward is enqueued (after ``after_sh``) that returns None or
         dict(flat, exp_avg, exp_avg_sq, lr={means3D, opacities, ts, scales, scales_t, rotations, rotations_r}, betas, eps, step): the
-        geometry backward then also takes the Adam step of the geometry parameters (fdgs_backward_out.adam; raw_params only);
-        ``sh_jacobian``: the forward ran with ``sh_jacobian=True`` (fdgs_backward_in.sh_jacobian; takes effect with ``sh_stage``)."""
+        geometry backward then also takes the Adam step of the geometry parameters (fdgs_backward_out.adam; raw_params only)."""
         dev = means3D.device
         # The reference always receives four dense tensors (autograd materialises zeros).  Here an image gradient may
         # be None = "no upstream gradient": the kernels then skip that term (colour-only backward when only
@@ -295,7 +291,7 @@ class _NativeRasterizer:
         radii_c, om_c = radii.contiguous(), out_means3D.contiguous()
         bin_ = _capi.FdgsBackwardIn(_capi._ptr(gin[0]), _capi._ptr(gin[1]), _capi._ptr(gin[2]), _capi._ptr(gin[3]),
                                     _capi._ptr(radii_c), _capi._ptr(om_c), _capi._ptr(geomBuffer),
-                                    _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R), int(bool(sh_jacobian)))
+                                    _capi._ptr(binningBuffer), _capi._ptr(imageBuffer), int(R))
         if accumulate and not grad_out:
             raise RuntimeError("fdgs: accumulate=True needs grad_out buffers that already hold gradients")
         if not per_view_outputs:

@@ -81,10 +81,6 @@ class StepPipeline:
         # backward (fdgs_backward_out.adam: the kernel has just completed their gradient) instead of by a launch of its own at the very end
         # of the step (FDGS_PIPELINE_GEO_ADAM=0: the separate launch, A/B); bit-identical parameters and moments
         self.fuse_geo_adam = os.environ.get("FDGS_PIPELINE_GEO_ADAM", "1") != "0"
-        # fdgs_forward_out.sh_jacobian: with a deferred SH gradient (every step of more than one view, and every fused step) the views'
-        # forwards also keep the coefficient sums their SH backward needs -- taken while the rows are on the chip for the colours -- and
-        # the SH backward reads no coefficient (FDGS_PIPELINE_SH_JAC=0: the backward evaluates them itself from the rows, A/B)
-        self.sh_jacobian = os.environ.get("FDGS_PIPELINE_SH_JAC", "1") != "0"
         self._geo_adam_done = False
         self._carry = None    # what the model looked like when the last step left its SH update running on stream A
         self.steps_carried = 0
@@ -213,8 +209,7 @@ class StepPipeline:
                     rs, xyz, feats, opacity, ts, scaling, scaling_t, rotation, rotation_r, prefilter_var, preprocessed=handles[b],
                     split_colour=(self.split_colour or (b == 0 and self.sA is not None and fuse)) and handles[b] is None,
                     colour_stream=self.sA if (b == 0 and self.sA is not None and fuse and handles[b] is None) else None,
-                    tile_cull=self.tile_cull, lazy=lazy and handles[b] is None, sparse_lists=self.sparse_lists and lazy and handles[b] is None,
-                    sh_jacobian=self.sh_jacobian and defer_sh and handles[b] is None)
+                    tile_cull=self.tile_cull, lazy=lazy and handles[b] is None, sparse_lists=self.sparse_lists and lazy and handles[b] is None)
                 ev = torch.cuda.Event()
                 ev.record(self.sF)
             with torch.cuda.stream(self.sB):
@@ -286,8 +281,7 @@ class StepPipeline:
                 grads = raw_backward(rs, xyz, out_means3D, radii, feats, opacity, ts, scaling, scaling_t, rotation,
                                      rotation_r, prefilter_var, geom, R, binb, img, g_color, None, None, None,
                                      self.sink, b > 0, grad_accum=self._gacc, after_sh=after_sh,
-                                     sh_stage=self._sh_stage[b] if defer_sh else None, per_view_outputs=False, geometry_adam=geo_adam,
-                                     sh_jacobian=self.sh_jacobian and defer_sh and handles[b] is None)
+                                     sh_stage=self._sh_stage[b] if defer_sh else None, per_view_outputs=False, geometry_adam=geo_adam)
                 # the small reduction of the loss VALUE: behind the backward (nothing of the step waits for it) -- or, with two streams, all
                 # views' reductions on stream F behind its last forward (below): stream B's chain is the step's critical path, and 4 x ~6 us
                 # of a one-workgroup kernel were part of it

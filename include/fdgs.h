@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FDGS_VERSION 503 /* 0.5.3 (round 6: fdgs_forward_out.sh_jacobian / fdgs_backward_in.sh_jacobian, fdgs_set_sparse_lists_budget; round 5: fdgs_forward_out.sparse_lists, .colour_stream).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
+#define FDGS_VERSION 502 /* 0.5.2 (round 6: fdgs_set_sparse_lists_budget; round 5: fdgs_forward_out.sparse_lists, .colour_stream).  Every struct below starts with `struct_size` = sizeof(the struct) as THIS header defines it
                             (the library answers FDGS_ERR_INVALID_ARG to any other value), and fdgs_version() must equal
                             FDGS_VERSION: a binding built against another revision of this header is turned away instead of
                             having the library read past the end of a shorter struct. */
@@ -179,15 +179,6 @@ typedef struct fdgs_forward_out
 	                         SH coefficients on it gets: geometry, binning and sort of the next view (which read no SH coefficient) next
 	                         to that update on the call's stream, the colours right behind it (fdgs.pipeline.StepPipeline, the first view
 	                         of a step).  Same device as the call's stream */
-	int32_t sh_jacobian;  /* 0: the forward evaluates the colours only.  1 (a TRAINING forward whose backward defers the SH gradient,
-	                         fdgs_backward_out.sh_stage): while a Gaussian's SH coefficients are on the chip for its colour, the preprocess also
-	                         takes the sums the SH backward needs from the very same coefficients -- d colour / d view direction (3 x 3) and
-	                         d colour / d time (3), evaluated as computeColorFromSH's backward does (backward.cu:172-481, at the direction
-	                         from the SHIFTED mean, Q4) -- and keeps them in the geometry buffer, 64 bytes per visible Gaussian.  A backward
-	                         called with fdgs_backward_in.sh_jacobian = 1 then never reads a coefficient: 12 M bytes per Gaussian travel
-	                         once per view instead of twice, and the mean / time gradients are the same bit for bit (the same
-	                         operations in the same order, only earlier).  Ignored without SH coefficients and by the view-batched
-	                         preprocess (fdgs_preprocess_batch: such a view's backward must say 0) */
 } fdgs_forward_out;
 
 /* fdgs_backward_out.adam: the scene's geometry tensors are slices of ONE flat parameter buffer `flat`; exp_avg / exp_avg_sq are
@@ -218,10 +209,6 @@ typedef struct fdgs_backward_in
 	const void* binning_buffer;
 	const void* image_buffer;
 	int32_t num_rendered;        /* R returned by forward (-1 from a lazy forward: fine) */
-	int32_t sh_jacobian;         /* 1: the forward that filled geom_buffer ran with fdgs_forward_out.sh_jacobian = 1 -- with a deferred SH
-	                                gradient (fdgs_backward_out.sh_stage) the SH backward takes the mean / time gradient and the stage
-	                                record from the stored sums and reads no coefficient.  Without sh_stage (dL_dsh wanted from this very
-	                                call) it is ignored.  0: the SH backward evaluates the sums itself */
 } fdgs_backward_in;
 
 /* Gradients; every non-NULL array is fully written by the call (no pre-zeroing
