@@ -191,3 +191,37 @@ def test_blend_bwd_inline_asm_register_allocation():
     spec.loader.exec_module(mod)
     sizes = [r[0] for r in mod.check()]
     assert 9 in sizes and 12 in sizes
+
+
+def test_register_budgets_of_the_built_kernels():
+    """Occupancy is part of the design (DESIGN.md sections 4 and 8): the per-Gaussian kernels are built without the SLP vectorizer, whose
+    packed operations on register pairs cost preprocess_fwd 62 VGPRs and preprocess_bwd 35; the SSIM forward filters four packed channels.
+    The VGPR counts of the gfx950 code the compiler produces with build.sh's flags are checked here, so that a flag that goes missing or a
+    compiler bump shows up as a failed test and not as a slower step."""
+    import re
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(ROOT, "4d-gaussian-splatting_amd", "csrc")
+    with open(os.path.join(csrc, "build.sh")) as f:
+        sh = f.read()
+    extra = dict(re.findall(r'\[(\w+)\]="([^"]*)"', re.search(r"declare -A EXTRA=\((.*?)\)\n", sh, re.S).group(1)))
+    common = re.search(r'COMMON="([^"]*)"', sh).group(1).replace("$ARCH", "gfx950").split()
+    budgets = {   # kernel name fragment -> (translation unit, most VGPRs, fewest waves per SIMD that means)
+        "preprocess_fwd_kernelILi0E": ("preprocess_fwd", 184, 2), "preprocess_fwd_kernelILi2E": ("preprocess_fwd", 168, 3),
+        "preprocess_bwd_kernelE": ("preprocess_bwd", 104, 4), "ssim_fwd_kernel": ("ssim", 96, 5), "ssim_bwd_kernel": ("ssim", 96, 5),
+    }
+
+    def vgprs(tu):
+        cmd = ["/opt/rocm/bin/hipcc"] + common + extra.get(tu, "").split() + ["-S", "--cuda-device-only", "-o", "-", os.path.join(csrc, tu + ".hip")]
+        asm = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+        return {m.group(1): (int(m.group(2)), int(m.group(3))) for m in
+                re.finditer(r"\.name:\s+(\S+)\n.*?\.vgpr_count:\s+(\d+)\n.*?\.vgpr_spill_count:\s+(\d+)", asm, re.S)}
+    tus = sorted({v[0] for v in budgets.values()})
+    with ThreadPoolExecutor(len(tus)) as ex:
+        got = dict(zip(tus, ex.map(vgprs, tus)))
+    for frag, (tu, most, waves) in budgets.items():
+        hits = {k: v for k, v in got[tu].items() if frag in k}
+        assert hits, (frag, list(got[tu]))
+        for name, (n, spills) in hits.items():
+            assert n <= most and spills == 0, "%s: %d VGPRs, %d spills (budget %d = %d waves per SIMD)" % (name, n, spills, most, waves)
+            assert 512 // ((n + 7) // 8 * 8) >= waves, (name, n)
