@@ -541,6 +541,13 @@ def c5_leg(args, dev, make_cams, pipe, B):
             e["algo_bytes"] = int(b)
             e["gbps"] = round(b / (ms / n * 1e-3) / 1e9, 1) if ms > 0 else None
             e["frac_of_hbm_peak"] = round(b / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None
+            # the bytes the kernel really moved (committed C5 counter passes, not this run) over THIS run's time: what the memory system was
+            # doing, next to what the algorithm needed (traffic / algo_bytes > 1: partial lines, read-modify-write of the gradient
+            # accumulators, the re-zeroing of the records)
+            tr = pmc_traffic(name, "C5")
+            if tr and ms > 0:
+                e["traffic"] = int(tr)
+                e["frac_of_hbm_peak_by_traffic"] = round(tr / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             total_bytes += b
         stages[name] = e
     # the timed two-stream steps, the dominant kernel re-measured live
