@@ -380,7 +380,7 @@ def test_step_pipeline_matches_autograd_step(gpu_device, overlap, fuse, B, batch
         got_losses += [float(l) for l in losses]
         assert len(results) == B and results[0]["render"].shape == (3, scene["H"], scene["W"])
     torch.cuda.synchronize()
-    np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=3e-5, atol=1e-6)   # (second step: behind one Adam step's float-atomics noise)
     # the gradients of the last step (float atomics: summation order differs run to run) and the parameters after two steps
     # (fuse_sh_adam: the SH gradient goes from the views' stages straight into Adam and is not materialised in the bucket)
     n_cmp = mp.offsets["_features"][0] if fuse else mp.flat.numel()
@@ -571,7 +571,9 @@ def test_step_pipeline_lazy_equals_waiting_and_redoes_an_overflowing_step(gpu_de
     # differs from run to run (a parameter may move by 2 lr): a handful of the ~14-37 k instances per view may come or go
     assert runs[True][2][:B] == runs[False][2][:B] and min(runs[True][2]) > 0, (runs[True][2], runs[False][2])
     assert all(abs(a - b) <= 1e-3 * b for a, b in zip(runs[True][2], runs[False][2])), (runs[True][2], runs[False][2])
-    np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=1e-5, atol=1e-6)
+    # (losses behind an Adam step carry its float-atomics noise, which grows step by step: 1e-5 of round 5 was met in every run so far,
+    # 2.6e-5 was seen once at step 8 of the overlap_steps test below; a forward that reads wrong lists is off by 1e-3 and more)
+    np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=3e-5, atol=1e-6)
     perr = (runs[True][0] - runs[False][0]).abs()
     assert (perr > 2e-3).float().mean().item() <= 2e-3 and perr.max().item() <= 0.25   # (Adam on float-atomics noise: see above)
 
@@ -617,8 +619,13 @@ def test_step_pipeline_overlap_steps_equals_plain(gpu_device):
     assert runs["overlap"][2] == steps - 4 and runs["plain"][2] == 0, (runs["overlap"][2], runs["plain"][2])
     np.testing.assert_allclose(runs["overlap"][1][:B], runs["plain"][1][:B], rtol=1e-6, atol=1e-7)      # first step: identical inputs
     noise = (runs["plain again"][0] - runs["plain"][0]).abs()
+    # the losses of the later steps carry the float-atomics noise of the Adam steps before them (it grows step by step: 2.6e-5 relative at
+    # step 8 in one run of ten, against a fixed bar of 2e-5): the bar is what two runs of the PLAIN pipeline differ by, with room, and
+    # never more than 1e-4 (a colour pass that does not wait for the SH update is off by ~1e-3)
+    la, lb = np.array(runs["plain"][1]), np.array(runs["plain again"][1])
+    loss_rtol = float(min(1e-4, max(2e-5, 4.0 * np.max(np.abs(la - lb) / np.abs(la)))))
     for other in ("overlap",):
-        np.testing.assert_allclose(runs[other][1], runs["plain"][1], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(runs[other][1], runs["plain"][1], rtol=loss_rtol, atol=1e-6)
         perr = (runs[other][0] - runs["plain"][0]).abs()
         # (Adam on float-atomics noise: a parameter whose gradient is noise around zero may move by 2 lr per step either way; the bar is
         # what two runs of the plain pipeline differ by, with room)

